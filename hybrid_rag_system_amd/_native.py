@@ -1,0 +1,91 @@
+"""ctypes binding of libhrs.so (the C ABI declared in include/hrs.h).
+
+The library holds gfx950 code only.  There is no CPU fallback: if the shared object is missing, or
+no MI355X is present when a context is created, the call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhrs.so")
+
+SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+MODE_AUTO, MODE_EXACT, MODE_MFMA = 0, 1, 2
+MAX_K = 128
+PAD_KEY = 0xFFFFFFFFFFFFFFFF
+
+EXPORTS = [
+    "hrs_version",
+    "hrs_last_error",
+    "hrs_ctx_create",
+    "hrs_ctx_destroy",
+    "hrs_corpus_register",
+    "hrs_corpus_release",
+    "hrs_corpus_stats",
+    "hrs_score_topk",
+    "hrs_score_stats",
+    "hrs_postings_register",
+    "hrs_postings_release",
+    "hrs_keyword_counts",
+    "hrs_fuse_sort",
+    "hrs_merge_topk",
+    "hrs_unpack_keys",
+    "hrs_synth_rows",
+    "hrs_synth_postings",
+]
+
+
+class HrsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libhrs.so once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HrsError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(hipcc --offload-arch=gfx950); this package has no CPU path"
+            )
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
+        sig = {
+            "hrs_version": ([], i32),
+            "hrs_last_error": ([C.c_char_p, C.c_size_t], i32),
+            "hrs_ctx_create": ([i32, C.POINTER(vp)], i32),
+            "hrs_ctx_destroy": ([vp], i32),
+            "hrs_corpus_register": ([vp, vp, i64, i32, i64, vp, C.POINTER(vp)], i32),
+            "hrs_corpus_release": ([vp, vp], i32),
+            "hrs_corpus_stats": ([vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)], i32),
+            "hrs_score_topk": ([vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], i32),
+            "hrs_score_stats": ([vp, vp, C.POINTER(i64)], i32),
+            "hrs_postings_register": ([vp, vp, vp, i64, i64, C.POINTER(vp)], i32),
+            "hrs_postings_release": ([vp, vp], i32),
+            "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),
+            "hrs_fuse_sort": ([vp, vp, vp, vp, i32, i32, dbl, i32, vp, vp, vp], i32),
+            "hrs_merge_topk": ([vp, vp, vp, i32, i32, i32, vp, vp, vp], i32),
+            "hrs_unpack_keys": ([vp, vp, i64, vp, vp, vp], i32),
+            "hrs_synth_rows": ([vp, u64, i64, i64, i32, i32, vp, vp], i32),
+            "hrs_synth_postings": ([vp, u64, i64, i64, i32, i32, vp, vp, vp], i32),
+        }
+        for name, (args, res) in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().hrs_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HrsError(f"{what} failed ({rc}): {last_error()}")

@@ -1,0 +1,210 @@
+// Context, error reporting, workspaces and the entry points that only dispatch.
+#include <stdarg.h>
+
+#include "hrs_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void hrs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int hrs_version(void) { return 1; }
+
+extern "C" int hrs_last_error(char* buf, size_t n) {
+    size_t len = strlen(g_err);
+    if (buf && n) {
+        size_t m = len < n - 1 ? len : n - 1;
+        memcpy(buf, g_err, m);
+        buf[m] = 0;
+    }
+    return (int)len;
+}
+
+int hrs_ws_reserve(hrs_ctx* ctx, hrs_workspace* ws, size_t bytes) {
+    (void)ctx;
+    if (ws->bytes >= bytes) return HRS_OK;
+    if (ws->ptr) {
+        HRS_CHECK_HIP(hipDeviceSynchronize());
+        HRS_CHECK_HIP(hipFree(ws->ptr));
+        ws->ptr = nullptr;
+        ws->bytes = 0;
+    }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&ws->ptr, want);
+    if (e != hipSuccess) {
+        hrs_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        ws->ptr = nullptr;
+        return HRS_ERR_NOMEM;
+    }
+    ws->bytes = want;
+    return HRS_OK;
+}
+
+extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
+    HRS_REQUIRE(out != nullptr, "hrs_ctx_create: out is null");
+    int ndev = 0;
+    HRS_CHECK_HIP(hipGetDeviceCount(&ndev));
+    HRS_REQUIRE(device >= 0 && device < ndev, "hrs_ctx_create: device %d out of range (have %d)", device, ndev);
+    HRS_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HRS_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        hrs_set_error("hrs_ctx_create: device %d is %s; this library holds gfx950 (MI355X) code only", device,
+                      prop.gcnArchName);
+        return HRS_ERR_UNSUPPORTED;
+    }
+    hrs_ctx* c = new hrs_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : HRS_NUM_CU;
+    hipError_t e = hipMalloc((void**)&c->stats_dev, 8 * sizeof(int64_t));
+    if (e != hipSuccess) {
+        delete c;
+        hrs_set_error("hrs_ctx_create: hipMalloc failed: %s", hipGetErrorString(e));
+        return HRS_ERR_NOMEM;
+    }
+    HRS_CHECK_HIP(hipMemset(c->stats_dev, 0, 8 * sizeof(int64_t)));
+    *out = c;
+    return HRS_OK;
+}
+
+extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
+    if (!ctx) return HRS_OK;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    if (ctx->ws_partial.ptr) hipFree(ctx->ws_partial.ptr);
+    if (ctx->ws_mfma.ptr) hipFree(ctx->ws_mfma.ptr);
+    if (ctx->ws_keys.ptr) hipFree(ctx->ws_keys.ptr);
+    if (ctx->stats_dev) hipFree(ctx->stats_dev);
+    delete ctx;
+    return HRS_OK;
+}
+
+extern "C" int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, int D, int64_t row_offset,
+                                   void* stream, hrs_corpus** out) {
+    HRS_REQUIRE(ctx && out, "hrs_corpus_register: null ctx/out");
+    HRS_REQUIRE(N >= 0 && (N == 0 || C_dev), "hrs_corpus_register: N=%lld with null matrix", (long long)N);
+    HRS_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "hrs_corpus_register: D=%d must be a multiple of 4 in (0, 8192]", D);
+    HRS_REQUIRE(row_offset >= 0 && N + row_offset < (1ll << 32), "hrs_corpus_register: rows beyond 2^32");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hrs_corpus* c = new hrs_corpus();
+    c->C = C_dev;
+    c->N = N;
+    c->D = D;
+    c->row_offset = row_offset;
+    int rc = hrs_build_shadow(ctx, c, (hipStream_t)stream);
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return HRS_OK;
+}
+
+extern "C" int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* c) {
+    if (!c) return HRS_OK;
+    if (ctx) hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    if (c->shadow) hipFree(c->shadow);
+    if (c->norm_stats) hipFree(c->norm_stats);
+    delete c;
+    return HRS_OK;
+}
+
+extern "C" int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* c, void* stream, double* mn, double* mx) {
+    HRS_REQUIRE(ctx && c, "hrs_corpus_stats: null handle");
+    double h[2] = {0, 0};
+    if (c->N > 0) {
+        HRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        HRS_CHECK_HIP(hipMemcpy(h, c->norm_stats, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    if (mn) *mn = h[0];
+    if (mx) *mx = h[1];
+    return HRS_OK;
+}
+
+__global__ void k_unpack(const uint64_t* keys, int64_t n, float* dist, int64_t* rows) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys[i];
+    bool pad = k == HRS_PAD_KEY;
+    if (dist) dist[i] = pad ? __builtin_inff() : orderable_f32((uint32_t)(k >> 32));
+    if (rows) rows[i] = pad ? -1 : (int64_t)(k & 0xFFFFFFFFull);
+}
+
+extern "C" int hrs_unpack_keys(hrs_ctx* ctx, const uint64_t* keys_dev, int64_t n, float* dist_dev, int64_t* rows_dev,
+                               void* stream) {
+    HRS_REQUIRE(ctx && keys_dev && n >= 0, "hrs_unpack_keys: bad arguments");
+    if (n == 0) return HRS_OK;
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys_dev, n,
+                       dist_dev, rows_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
+                              const uint8_t* row_mask_dev, int mode, uint64_t* keys_dev, float* dist_dev,
+                              int64_t* rows_dev, void* stream) {
+    HRS_REQUIRE(ctx && c, "hrs_score_topk: null handle");
+    HRS_REQUIRE(B >= 0 && (B == 0 || Q_dev), "hrs_score_topk: B=%d with null queries", B);
+    HRS_REQUIRE(k >= 1 && k <= HRS_MAX_K, "hrs_score_topk: k=%d outside [1, %d]", k, HRS_MAX_K);
+    HRS_REQUIRE(space >= 0 && space <= 2, "hrs_score_topk: unknown space %d", space);
+    HRS_REQUIRE(mode >= 0 && mode <= 2, "hrs_score_topk: unknown mode %d", mode);
+    HRS_REQUIRE(!(mode == HRS_MODE_MFMA && row_mask_dev), "hrs_score_topk: a row mask needs EXACT mode");
+    if (B == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t* keys = keys_dev;
+    if (!keys) {
+        int rc0 = hrs_ws_reserve(ctx, &ctx->ws_keys, (size_t)B * k * sizeof(uint64_t));
+        if (rc0) return rc0;
+        keys = (uint64_t*)ctx->ws_keys.ptr;
+    }
+    bool use_mfma;
+    if (mode == HRS_MODE_EXACT)
+        use_mfma = false;
+    else if (mode == HRS_MODE_MFMA)
+        use_mfma = true;
+    else
+        use_mfma = !row_mask_dev && B > 4 && c->N >= 65536;
+    if (use_mfma && (c->N < 4096 || c->N < (int64_t)k * 64)) use_mfma = false;
+
+    int rc = use_mfma ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, keys, st)
+                      : hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, st);
+    if (rc == HRS_OK && (dist_dev || rows_dev))
+        rc = hrs_unpack_keys(ctx, keys, (int64_t)B * k, dist_dev, rows_dev, stream);
+    return rc;
+}
+
+extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
+    HRS_REQUIRE(ctx && out, "hrs_score_stats: null argument");
+    HRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int64_t h[8];
+    HRS_CHECK_HIP(hipMemcpy(h, ctx->stats_dev, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0];
+    out[1] = h[1];
+    out[2] = h[2];
+    return HRS_OK;
+}
+
+extern "C" int hrs_postings_register(hrs_ctx* ctx, const int64_t* doc_offs_dev, const int32_t* term_ids_dev,
+                                     int64_t N, int64_t row_offset, hrs_postings** out) {
+    HRS_REQUIRE(ctx && out && doc_offs_dev, "hrs_postings_register: null argument");
+    HRS_REQUIRE(N >= 0 && row_offset >= 0, "hrs_postings_register: negative size");
+    hrs_postings* p = new hrs_postings();
+    p->doc_offs = doc_offs_dev;
+    p->term_ids = term_ids_dev;
+    p->N = N;
+    p->row_offset = row_offset;
+    *out = p;
+    return HRS_OK;
+}
+
+extern "C" int hrs_postings_release(hrs_ctx* ctx, hrs_postings* p) {
+    (void)ctx;
+    delete p;
+    return HRS_OK;
+}

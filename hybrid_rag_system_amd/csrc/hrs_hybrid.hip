@@ -1,0 +1,185 @@
+// Keyword presence counts over forward-CSR postings, score fusion + stable order, cross-shard merge.
+#include "hrs_internal.h"
+
+// One wave per (query, candidate): the 64 lanes read the row's term list coalesced and compare each
+// term with the query's terms (wave-uniform, read through the scalar path); a ballot per query term
+// gives its presence.  Integer work only.
+__global__ __launch_bounds__(256) void k_keyword_counts(const int64_t* __restrict__ doc_offs,
+                                                        const int32_t* __restrict__ term_ids, int64_t N,
+                                                        int64_t row_offset, const int32_t* __restrict__ q_terms,
+                                                        const int32_t* __restrict__ q_term_offs,
+                                                        const int64_t* __restrict__ cand_rows, int B, int c,
+                                                        int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)B * c) return;
+    const int b = (int)(pair / c);
+    int64_t row = cand_rows[pair] - row_offset;
+    int n = 0;
+    if (cand_rows[pair] >= 0 && row >= 0 && row < N) {
+        const int64_t p0 = doc_offs[row], p1 = doc_offs[row + 1];
+        const int t0 = q_term_offs[b], t1 = q_term_offs[b + 1];
+        for (int tb = t0; tb < t1; tb += 64) {
+            // lanes hold up to 64 query terms; presence bit per lane
+            const int nt = min(64, t1 - tb);
+            const int my = lane < nt ? q_terms[tb + lane] : -1;
+            bool found = false;
+            for (int64_t p = p0; p < p1; p += 64) {
+                const int m = (int)min((int64_t)64, p1 - p);
+                const int dt = lane < m ? term_ids[p + lane] : -2;
+                // every lane checks its query term against the 64 document terms of this block
+                for (int j = 0; j < m; ++j) {
+                    int v = __shfl(dt, j);
+                    found |= (v == my);
+                }
+            }
+            unsigned long long bal = __ballot(found && lane < nt);
+            n += __popcll(bal);
+        }
+    }
+    if (lane == 0) counts[pair] = n;
+}
+
+extern "C" int hrs_keyword_counts(hrs_ctx* ctx, hrs_postings* p, const int32_t* q_terms_dev,
+                                  const int32_t* q_term_offs_dev, const int64_t* cand_rows_dev, int B, int c,
+                                  int32_t* counts_dev, void* stream) {
+    HRS_REQUIRE(ctx && p && q_term_offs_dev && cand_rows_dev && counts_dev, "hrs_keyword_counts: null argument");
+    HRS_REQUIRE(B >= 0 && c >= 0, "hrs_keyword_counts: negative size");
+    if ((int64_t)B * c == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    const int64_t pairs = (int64_t)B * c;
+    hipLaunchKernelGGL(k_keyword_counts, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       p->doc_offs, p->term_ids, p->N, p->row_offset, q_terms_dev, q_term_offs_dev, cand_rows_dev, B,
+                       c, counts_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+// One block per query, one thread per candidate (c <= 256).  Python-float arithmetic: every product
+// and the sum are separately rounded fp64 operations (no contraction into an fma).
+__global__ __launch_bounds__(256) void k_fuse_sort(const float* __restrict__ dist, const int32_t* __restrict__ counts,
+                                                   const int32_t* __restrict__ q_term_offs, int c, double boost,
+                                                   int n, double* __restrict__ combined, int32_t* __restrict__ perm) {
+    __shared__ double comb[256];
+    __shared__ int valid[256];
+    const int b = blockIdx.x, j = threadIdx.x;
+    double mine = 0.0;
+    int ok = 0;
+    if (j < c) {
+        const float d32 = dist[(size_t)b * c + j];
+        ok = !(d32 == __builtin_inff());
+        if (ok) {
+            const double d = (double)d32;
+            double sem = __dsub_rn(1.0, d);
+            if (!(sem > 0.0)) sem = 0.0;
+            const int m = q_term_offs[b + 1] - q_term_offs[b];
+            const double kw = m > 0 ? __ddiv_rn((double)counts[(size_t)b * c + j], (double)m) : 0.0;
+            const double w = __dsub_rn(1.0, boost);
+            mine = __dadd_rn(__dmul_rn(sem, w), __dmul_rn(kw, boost));
+        }
+    }
+    comb[j] = mine;
+    valid[j] = ok;
+    __syncthreads();
+    if (j < c && ok) {
+        // rank under (combined descending, candidate index ascending) == a stable descending sort
+        int rank = 0;
+        for (int i = 0; i < c; ++i) {
+            if (!valid[i]) continue;
+            const double o = comb[i];
+            rank += (o > mine) || (o == mine && i < j);
+        }
+        if (rank < n) {
+            combined[(size_t)b * n + rank] = mine;
+            perm[(size_t)b * n + rank] = j;
+        }
+    }
+    // slots past the number of valid candidates
+    __syncthreads();
+    int nv = 0;
+    for (int i = 0; i < c; ++i) nv += valid[i];
+    for (int i = nv + j; i < n; i += 256) {
+        combined[(size_t)b * n + i] = -1.0;
+        perm[(size_t)b * n + i] = -1;
+    }
+}
+
+extern "C" int hrs_fuse_sort(hrs_ctx* ctx, const float* dist_dev, const int32_t* counts_dev,
+                             const int32_t* q_term_offs_dev, int B, int c, double boost, int n, double* combined_dev,
+                             int32_t* perm_dev, void* stream) {
+    HRS_REQUIRE(ctx && dist_dev && counts_dev && q_term_offs_dev && combined_dev && perm_dev,
+                "hrs_fuse_sort: null argument");
+    HRS_REQUIRE(c >= 1 && c <= 256, "hrs_fuse_sort: c=%d outside [1, 256]", c);
+    HRS_REQUIRE(n >= 1, "hrs_fuse_sort: n=%d < 1", n);
+    if (B <= 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_fuse_sort, dim3(B), dim3(256), 0, (hipStream_t)stream, dist_dev, counts_dev, q_term_offs_dev,
+                       c, boost, n, combined_dev, perm_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+// Cross-shard merge: keys are globally unique (the row is part of the key), so the payload of each
+// output key is found again by position after sorting (key, source slot) pairs.
+__global__ __launch_bounds__(256) void k_merge_topk(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                    int G, int B, int k, uint64_t* __restrict__ out_keys,
+                                                    int32_t* __restrict__ out_vals) {
+    __shared__ uint64_t s[2048];
+    __shared__ int32_t v[2048];
+    const int b = blockIdx.x;
+    const int n = G * k;
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 256) {
+        if (i < n) {
+            const int g = i / k, j = i % k;
+            const size_t src = ((size_t)g * B + b) * k + j;
+            s[i] = keys[src];
+            v[i] = vals ? vals[src] : 0;
+        } else {
+            s[i] = HRS_PAD_KEY;
+            v[i] = 0;
+        }
+    }
+    __syncthreads();
+    // rank-based selection of the k smallest: n <= 2048, each thread ranks n/256 entries
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint64_t mine = s[i];
+        if (mine == HRS_PAD_KEY) continue;
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const uint64_t o = s[t];
+            rank += (o < mine) || (o == mine && t < i);
+        }
+        if (rank < k) {
+            out_keys[(size_t)b * k + rank] = mine;
+            if (out_vals) out_vals[(size_t)b * k + rank] = v[i];
+        }
+    }
+    __syncthreads();
+    int nv = 0;
+    for (int t = threadIdx.x; t < n; t += 256) nv += s[t] != HRS_PAD_KEY;
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    atomicAdd(&total, nv);
+    __syncthreads();
+    for (int i = total + threadIdx.x; i < k; i += 256) {
+        out_keys[(size_t)b * k + i] = HRS_PAD_KEY;
+        if (out_vals) out_vals[(size_t)b * k + i] = 0;
+    }
+}
+
+extern "C" int hrs_merge_topk(hrs_ctx* ctx, const uint64_t* keys_dev, const int32_t* vals_dev, int G, int B, int k,
+                              uint64_t* out_keys_dev, int32_t* out_vals_dev, void* stream) {
+    HRS_REQUIRE(ctx && keys_dev && out_keys_dev, "hrs_merge_topk: null argument");
+    HRS_REQUIRE(G >= 1 && k >= 1 && (int64_t)G * k <= 2048, "hrs_merge_topk: G*k=%lld outside [1, 2048]",
+                (long long)G * k);
+    HRS_REQUIRE(!(out_vals_dev && !vals_dev), "hrs_merge_topk: out_vals without vals");
+    if (B <= 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), 0, (hipStream_t)stream, keys_dev, vals_dev, G, B, k,
+                       out_keys_dev, out_vals_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}

@@ -1,0 +1,131 @@
+// Internal declarations shared by the translation units of libhrs.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hrs.h"
+
+#define HRS_NUM_CU 256      // MI355X: 8 XCDs x 32 CUs
+#define HRS_EXACT_CB 512    // per-query candidate buffer of the exact scan (keys)
+#define HRS_CAND_CAP 4096   // per-query candidate list of the MFMA scan
+#define HRS_RESCORE 256     // candidates re-scored exactly per query
+#define HRS_MAX_STREAMS 1024  // per-query running maxima written by the sampling pass
+
+void hrs_set_error(const char* fmt, ...);
+
+#define HRS_CHECK_HIP(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            hrs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return HRS_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define HRS_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            hrs_set_error(__VA_ARGS__); \
+            return HRS_ERR_ARG;       \
+        }                             \
+    } while (0)
+
+struct hrs_workspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct hrs_ctx {
+    int device = 0;
+    int num_cu = HRS_NUM_CU;
+    hrs_workspace ws_partial;  // exact scan: per (query, workgroup) top-k keys, and merge ping-pong
+    hrs_workspace ws_mfma;     // MFMA scan: bf16 queries, maxima, tau, counters, candidate lists
+    hrs_workspace ws_keys;     // result keys when the caller asks only for distances / rows
+    int64_t* stats_dev = nullptr;  // [8] counters of the last MFMA call
+};
+
+struct hrs_corpus {
+    const float* C = nullptr;  // caller-owned fp32 [N, D]
+    int64_t N = 0;
+    int D = 0;
+    int64_t row_offset = 0;
+    __bf16* shadow = nullptr;  // owned: bf16 [Npad, Dpad], zero padded
+    int64_t Npad = 0;
+    int Dpad = 0;
+    double* norm_stats = nullptr;  // owned: [2] = {min |c|^2, max |c|^2} as doubles
+};
+
+struct hrs_postings {
+    const int64_t* doc_offs = nullptr;
+    const int32_t* term_ids = nullptr;
+    int64_t N = 0;
+    int64_t row_offset = 0;
+};
+
+int hrs_ws_reserve(hrs_ctx* ctx, hrs_workspace* ws, size_t bytes);
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t pack_key(float d32, uint32_t row) {
+    return ((uint64_t)f32_orderable(d32) << 32) | row;
+}
+
+// Bitonic sort of n (power of two) uint64 keys in LDS, ascending; all threads of the block call it.
+__device__ __forceinline__ void bitonic_sort_u64(uint64_t* s, int n, int tid, int nthreads) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < n; i += nthreads) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t a = s[i], b = s[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// LDS-DMA: 16 bytes per lane from (scalar base + per-lane byte offset) to LDS at lds_addr + lane*16.
+// Written as inline asm so that the compiler neither counts it nor drains it with a vmcnt(0) before
+// unrelated LDS reads; the caller owns the s_waitcnt vmcnt(N) that retires it.  M0 (the DMA's LDS
+// base) is compiler-reserved, hence saved and restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* sbase, int voff, uint32_t lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_addr)
+        : "memory");
+}
+// A pointer the compiler can prove wave-uniform (it is, by construction, at every call site).
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// Launchers implemented in the kernel files.
+int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
+                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st);
+int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
+                    hipStream_t st);
+int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, hipStream_t st);

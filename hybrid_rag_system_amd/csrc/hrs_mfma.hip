@@ -1,0 +1,542 @@
+// Large-batch scoring on the matrix cores: bf16 MFMA scan with a threshold filter, then an exact
+// fp64 re-score of the surviving candidates and a proof that the top-k is the exact one.
+//
+//   1. k_convert_q      queries fp32 -> bf16 (+ squared norms)
+//   2. k_mfma_scan<PRE> a sampled subset of corpus tiles: per (query, stream) running maximum
+//   3. k_pick_tau       per query: tau = j-th largest stream maximum  (a LOWER bound of the j-th
+//                       largest sampled score), chosen so that a few hundred rows exceed it
+//   4. k_mfma_scan<MAIN> the whole corpus: every (query, row) with score > tau is appended to the
+//                       query's candidate list (global atomics; a few hundred per query)
+//   5. k_select_rescore per query: sort candidates by approximate score, re-score the best 256
+//                       exactly (fp64, the oracle's operations), sort by (fp32 distance, row) and
+//                       accept iff the k-th exact distance is provably below anything outside the
+//                       re-scored set (bf16 rounding bound); otherwise the query is queued for
+//   6. the exact scan   (hrs_exact.hip), driven by the device-side queue; no host round trip.
+//
+// Scan kernel geometry (per CU: one workgroup of 8 waves, two per SIMD):
+// each wave keeps the B-operand fragments of 32 queries for the WHOLE depth D in registers (D/4
+// VGPRs); 64-row corpus tiles (bf16) stream through a 3-deep LDS ring by LDS-DMA and are the A
+// operand, shared by the 8 waves (256 queries per workgroup).  D(32x32) = A(corpus rows) x B(queries)
+// puts the query on the lane, so the filter threshold is one VGPR.
+#include "hrs_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MF_QPW 32    // queries per wave (one MFMA tile)
+#define MF_QPB 256   // queries per workgroup
+#define MF_EPS_BASE 0.0039101
+#define MF_EPS_PER_D 2.4e-7
+
+struct MfmaArgs {
+    const __bf16* shadow;  // [Npad][Dpad]
+    const __bf16* qb;      // [Bpad][Dpad]
+    int64_t N;
+    int64_t tiles;         // ceil(N / TR)
+    int64_t row_offset;
+    int nqg;               // query groups of 256 (1, 2 or 4); nslices = 256 / nqg
+    int ss;                // sampling stride of the PRE pass (tiles)
+    float* maxima;         // [Bpad][HRS_MAX_STREAMS]
+    const float* tau;      // [Bpad]
+    int* cnt;              // [Bpad]
+    uint64_t* cand;        // [Bpad][HRS_CAND_CAP]
+};
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+template <int KS, int TR, bool PRE>
+__global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
+    constexpr int QT = 1;
+    constexpr int DP = KS * 16;               // padded depth (elements)
+    constexpr int RB = DP * 2;                // row bytes
+    constexpr int TILE_BYTES = TR * RB;
+    constexpr int IPW = TR * KS / 256;        // LDS-DMA instructions per wave per tile
+    constexpr int NSUB = TR / 32;
+    constexpr int PPR = 2 * KS;               // 16-byte pieces per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, i = lane & 31;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int qg = loc % a.nqg;
+    const int nslices = HRS_NUM_CU / a.nqg;
+    const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
+    const int q0 = qg * MF_QPB + wv * MF_QPW;
+
+    bf16x8 qf[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            qf[qt][s] = *(const bf16x8*)(a.qb + (size_t)(q0 + qt * 32 + i) * DP + s * 16 + h * 8);
+
+    float tau[QT];
+    float mx[QT][NSUB];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        tau[qt] = PRE ? 0.f : a.tau[q0 + qt * 32 + i];
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) mx[qt][sb] = -__builtin_inff();
+    }
+    // every query fragment must have landed before the loop: the compiler would otherwise place its
+    // partial vmcnt waits at their first use inside the loop, where they would drain the LDS-DMA ring
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
+
+    const int64_t t_begin = a.tiles * slice / nslices;
+    const int64_t t_end = a.tiles * (slice + 1) / nslices;
+    const int64_t count = PRE ? (t_end - t_begin) / a.ss : (t_end - t_begin);
+    const int64_t full_tiles = a.N / TR;  // tiles without padding rows
+
+    auto tile_at = [&](int64_t n) -> int64_t {
+        if (n >= count) n = count - 1;
+        if (!PRE) return t_begin + n;
+        int64_t t = t_begin + n * a.ss + (int64_t)(hash32((uint32_t)(slice * 0x9E3779B1u + n)) % (uint32_t)a.ss);
+        if (t >= full_tiles) t = full_tiles - 1;
+        return t < 0 ? 0 : t;
+    };
+    // per-lane source offsets of this wave's DMA pieces (bytes from the tile base): piece p of row r
+    // lands at LDS position p ^ (r & 15) of that row (the read side applies the same XOR)
+    int srcoff[IPW];
+#pragma unroll
+    for (int ii = 0; ii < IPW; ++ii) {
+        const int g = (wv * IPW + ii) * 64 + lane;
+        const int r = g / PPR, p = g % PPR;
+        srcoff[ii] = r * RB + ((p ^ (r & 15)) << 4);
+    }
+    const uint32_t lds0 = lds_addr_of(smem);
+    auto issue = [&](int64_t n, int buf) {
+        const char* base = uniform_ptr((const char*)a.shadow + tile_at(n) * (int64_t)TILE_BYTES);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + wv * (IPW * 1024));
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+    };
+    // read side: k-step s of row i wants piece 2s+h, stored at (2s+h) ^ (i&15).  With v = h ^ (i&15)
+    // the low four bits are ((2s)&15) ^ v: eight per-lane bases, everything else is an immediate.
+    int bc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bc[c] = (int)lds0 + i * RB + (((2 * c) ^ (h ^ (i & 15))) << 4);
+
+    if (count > 0) {
+        issue(0, 0);
+        issue(1, 1);
+        int buf = 0;
+        for (int64_t n = 0; n < count; ++n) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            {
+                int nb = buf + 2;
+                if (nb >= 3) nb -= 3;
+                issue(n + 2, nb);
+            }
+            const int64_t tile = tile_at(n);
+            typedef const __attribute__((address_space(3))) char* lds_cptr;
+            lds_cptr tb[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
+#pragma unroll
+            for (int sb = 0; sb < NSUB; ++sb) {
+                f32x16 acc[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
+                constexpr int PF = 4;  // A fragments in flight
+                bf16x8 av[KS];
+#pragma unroll
+                for (int s = 0; s < PF && s < KS; ++s)
+                    av[s] = *(const __attribute__((address_space(3))) bf16x8*)(tb[s & 7] + sb * 32 * RB + (s >> 3) * 256);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (s + PF < KS)
+                        av[s + PF] = *(const __attribute__((address_space(3))) bf16x8*)(tb[(s + PF) & 7] + sb * 32 * RB +
+                                                                                       ((s + PF) >> 3) * 256);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], qf[qt][s], acc[qt], 0, 0, 0);
+                }
+                // schedule: PF LDS reads up front, then one MFMA per further read, then the last PF MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+                for (int s = 0; s < KS - PF; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, QT * PF, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float m = acc[qt][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qt][r]);
+                    if (PRE) {
+                        mx[qt][sb] = fmaxf(mx[qt][sb], m);
+                    } else if (m > tau[qt]) {
+                        const int q = q0 + qt * 32 + i;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (acc[qt][r] > tau[qt]) {
+                                const int64_t row = tile * TR + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (row < a.N) {
+                                    const int pos = atomicAdd(&a.cnt[q], 1);
+                                    if (pos < HRS_CAND_CAP)
+                                        a.cand[(size_t)q * HRS_CAND_CAP + pos] =
+                                            ((uint64_t)(~f32_orderable(acc[qt][r])) << 32) |
+                                            (uint32_t)(row + a.row_offset);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            buf = buf + 1 == 3 ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (PRE) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int sb = 0; sb < NSUB; ++sb)
+                a.maxima[(size_t)(q0 + qt * 32 + i) * HRS_MAX_STREAMS + (slice * 2 + h) * NSUB + sb] = mx[qt][sb];
+    }
+}
+
+// fp32 [N, D] -> bf16 [Npad, Dpad] (zero padded) and min/max squared row norm. One wave per row.
+__global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ C, int64_t N, int D, int64_t Npad,
+                                                      int Dpad, __bf16* __restrict__ out,
+                                                      unsigned long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= Npad) return;
+    double ss = 0.0;
+    for (int c = lane; c < Dpad; c += 64) {
+        float v = (r < N && c < D) ? C[r * D + c] : 0.f;
+        out[r * Dpad + c] = (__bf16)v;
+        ss += (double)v * (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0 && r < N) {
+        // non-negative doubles order like their bit patterns
+        atomicMin(&stats[0], (unsigned long long)__double_as_longlong(ss));
+        atomicMax(&stats[1], (unsigned long long)__double_as_longlong(ss));
+    }
+}
+
+__global__ void k_init_stats(unsigned long long* stats) {
+    stats[0] = (unsigned long long)__double_as_longlong(1e300);
+    stats[1] = 0ull;
+}
+
+int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, hipStream_t st) {
+    (void)ctx;
+    c->Dpad = (c->D + 127) / 128 * 128;
+    c->Npad = (c->N + 63) / 64 * 64 + 64;  // one spare tile: clamped prefetches stay in bounds
+    if (c->N == 0) return HRS_OK;
+    hipError_t e = hipMalloc((void**)&c->norm_stats, 2 * sizeof(double));
+    if (e == hipSuccess && c->Dpad <= 512) e = hipMalloc((void**)&c->shadow, (size_t)c->Npad * c->Dpad * sizeof(__bf16));
+    if (e != hipSuccess) {
+        hrs_set_error("corpus shadow allocation failed: %s", hipGetErrorString(e));
+        if (c->norm_stats) hipFree(c->norm_stats);
+        c->norm_stats = nullptr;
+        return HRS_ERR_NOMEM;
+    }
+    hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(1), 0, st, (unsigned long long*)c->norm_stats);
+    if (c->shadow) {
+        hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)((c->Npad + 3) / 4)), dim3(256), 0, st, c->C, c->N, c->D,
+                           c->Npad, c->Dpad, c->shadow, (unsigned long long*)c->norm_stats);
+    }
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+// Queries fp32 [B, D] -> bf16 [Bpad, Dpad] (zero padded), squared norms in fp64. One wave per query.
+__global__ __launch_bounds__(256) void k_convert_q(const float* __restrict__ Q, int B, int D, int Bpad, int Dpad,
+                                                   __bf16* __restrict__ qb, double* __restrict__ qn2) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Bpad) return;
+    double ss = 0.0;
+    for (int c = lane; c < Dpad; c += 64) {
+        float v = (q < B && c < D) ? Q[(size_t)q * D + c] : 0.f;
+        qb[(size_t)q * Dpad + c] = (__bf16)v;
+        ss += (double)v * (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) qn2[q] = ss;
+}
+
+// tau[q] = j-th largest of the query's M stream maxima; also clears the candidate counter.
+__global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxima, int M, int j, float* __restrict__ tau,
+                                                  int* __restrict__ cnt) {
+    __shared__ uint64_t s[HRS_MAX_STREAMS];
+    const int q = blockIdx.x;
+    int n2 = 1;
+    while (n2 < M) n2 <<= 1;
+    for (int t = threadIdx.x; t < n2; t += 256) {
+        // descending by value: key = ~orderable; -inf streams (no sample) sort last
+        s[t] = t < M ? (uint64_t)(~f32_orderable(maxima[(size_t)q * HRS_MAX_STREAMS + t])) : HRS_PAD_KEY;
+    }
+    bitonic_sort_u64(s, n2, threadIdx.x, 256);
+    if (threadIdx.x == 0) {
+        int jj = j < M ? j : M;
+        float v = orderable_f32(~(uint32_t)s[jj - 1]);
+        tau[q] = v;
+        cnt[q] = 0;
+    }
+}
+
+struct SelectArgs {
+    const float* C;
+    const float* Q;
+    int D;
+    int64_t N;
+    int64_t row_offset;
+    int B;
+    int k;
+    const int* cnt;
+    const uint64_t* cand;
+    const float* tau;
+    const double* qn2;
+    const double* norm_stats;
+    double eps_rel;
+    uint64_t* keys_out;  // [B][k]
+    int32_t* qlist;      // queue of queries for the exact fallback
+    int32_t* nflag;
+    long long* stats;    // [0] fallbacks, [1] max candidates, [2] overflows
+    int qbase;           // first query of this chunk
+};
+
+template <int SPACE>
+__global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
+    __shared__ uint64_t s[HRS_CAND_CAP];
+    __shared__ uint64_t ek[HRS_RESCORE];
+    const int ql = blockIdx.x;       // query within the chunk
+    const int q = a.qbase + ql;      // query in the caller's batch
+    const int tid = threadIdx.x;
+    const int craw = a.cnt[ql];
+    const int c = craw < HRS_CAND_CAP ? craw : HRS_CAND_CAP;
+    const bool overflow = craw > HRS_CAND_CAP;
+    int n2 = 256;
+    while (n2 < c) n2 <<= 1;
+    for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP + t] : HRS_PAD_KEY;
+    bitonic_sort_u64(s, n2, tid, 256);
+    const int R = c < HRS_RESCORE ? c : HRS_RESCORE;
+    uint64_t mine = HRS_PAD_KEY;
+    if (tid < R) {
+        const uint32_t grow = (uint32_t)(s[tid] & 0xFFFFFFFFull);
+        const float* cr = a.C + (size_t)((int64_t)grow - a.row_offset) * a.D;
+        const float* qr = a.Q + (size_t)q * a.D;
+        double acc = 0.0, nc = 0.0;
+        for (int d0 = 0; d0 < a.D; d0 += 4) {
+            const float4 cv = *(const float4*)(cr + d0);
+            const float4 qv = *(const float4*)(qr + d0);
+            const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
+            const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
+            if (SPACE == HRS_SPACE_L2) {
+                const double e0 = q0 - c0, e1 = q1 - c1, e2 = q2 - c2, e3 = q3 - c3;
+                acc = fma(e0, e0, acc);
+                acc = fma(e1, e1, acc);
+                acc = fma(e2, e2, acc);
+                acc = fma(e3, e3, acc);
+            } else {
+                acc = fma(q0, c0, acc);
+                acc = fma(q1, c1, acc);
+                acc = fma(q2, c2, acc);
+                acc = fma(q3, c3, acc);
+                if (SPACE == HRS_SPACE_COSINE) {
+                    nc = fma(c0, c0, nc);
+                    nc = fma(c1, c1, nc);
+                    nc = fma(c2, c2, nc);
+                    nc = fma(c3, c3, nc);
+                }
+            }
+        }
+        double d;
+        if (SPACE == HRS_SPACE_L2) {
+            d = acc;
+        } else if (SPACE == HRS_SPACE_IP) {
+            d = 1.0 - acc;
+        } else {
+            // the oracle's |q|^2 is a sequential fp64 sum: recompute it the same way
+            double nq = 0.0;
+            for (int d0 = 0; d0 < a.D; ++d0) nq = fma((double)qr[d0], (double)qr[d0], nq);
+            d = (nq == 0.0 || nc == 0.0) ? 1.0 : 1.0 - acc / (sqrt(nq) * sqrt(nc));
+        }
+        mine = pack_key((float)d, grow);
+    }
+    ek[tid] = mine;
+    bitonic_sort_u64(ek, HRS_RESCORE, tid, 256);
+    __shared__ int ok;
+    if (tid == 0) {
+        bool accept = !overflow && R >= a.k;
+        if (accept) {
+            // best approximate score of anything that was not re-scored
+            const float A = c > R ? orderable_f32(~(uint32_t)(s[R] >> 32)) : a.tau[ql];
+            const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
+            const double sb = (double)A + a.eps_rel * sqrt(qn) * sqrt(ncmax) + 1e-30;
+            double dmin;
+            if (SPACE == HRS_SPACE_L2)
+                dmin = qn + ncmin - 2.0 * sb;
+            else if (SPACE == HRS_SPACE_IP)
+                dmin = 1.0 - sb;
+            else
+                dmin = qn > 0.0 ? 1.0 - sb / (sqrt(qn) * sqrt(sb > 0.0 ? ncmin : ncmax)) : 2.0;
+            const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
+            accept = dk + 1e-6 * (1.0 + fabs(dmin)) < dmin;
+        }
+        ok = accept;
+        atomicMax((unsigned long long*)&a.stats[1], (unsigned long long)craw);
+        if (overflow) atomicAdd((unsigned long long*)&a.stats[2], 1ull);
+        if (!accept) {
+            atomicAdd((unsigned long long*)&a.stats[0], 1ull);
+            const int p = atomicAdd(a.nflag, 1);
+            a.qlist[p] = q;
+        }
+    }
+    __syncthreads();
+    if (ok)
+        for (int t = tid; t < a.k; t += 256) a.keys_out[(size_t)q * a.k + t] = ek[t];
+}
+
+template <int KS, int TR>
+static int launch_scan(const MfmaArgs& a, bool pre, hipStream_t st) {
+    const size_t lds = (size_t)3 * TR * KS * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (pre)
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+static int tile_rows_for(int Dpad) { return Dpad <= 384 ? 64 : 32; }
+
+int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
+                    hipStream_t st) {
+    if (!c->shadow || c->Dpad > 512 || ctx->num_cu != HRS_NUM_CU) {
+        // no matrix-core kernel for this shape: the exact scan gives the same answer
+        return hrs_launch_exact(ctx, c, Q, B, k, space, nullptr, nullptr, nullptr, keys_out, st);
+    }
+    const int Dpad = c->Dpad, KS = Dpad / 16, TR = tile_rows_for(Dpad);
+    const int BC = 1024;  // queries per chunk
+    // workspace carve
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_ctrl = carve(256);
+    const size_t o_qlist = carve((size_t)B * sizeof(int32_t));
+    const size_t o_qb = carve((size_t)BC * Dpad * sizeof(__bf16));
+    const size_t o_qn = carve((size_t)BC * sizeof(double));
+    const size_t o_max = carve((size_t)BC * HRS_MAX_STREAMS * sizeof(float));
+    const size_t o_tau = carve((size_t)BC * sizeof(float));
+    const size_t o_cnt = carve((size_t)BC * sizeof(int));
+    const size_t o_cand = carve((size_t)BC * HRS_CAND_CAP * sizeof(uint64_t));
+    int rc = hrs_ws_reserve(ctx, &ctx->ws_mfma, off);
+    if (rc) return rc;
+    char* ws = (char*)ctx->ws_mfma.ptr;
+    int32_t* nflag = (int32_t*)(ws + o_ctrl);
+    int32_t* qlist = (int32_t*)(ws + o_qlist);
+    HRS_CHECK_HIP(hipMemsetAsync(nflag, 0, 256, st));
+    HRS_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 8 * sizeof(int64_t), st));
+
+    const int64_t tiles = (c->N + TR - 1) / TR;
+    for (int qbase = 0; qbase < B; qbase += BC) {
+        const int bc = B - qbase < BC ? B - qbase : BC;
+        const int bpad = bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024);
+        const int nqg = bpad / MF_QPB;
+        const int nslices = HRS_NUM_CU / nqg;
+        hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
+                           bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn));
+        MfmaArgs a;
+        a.shadow = c->shadow;
+        a.qb = (const __bf16*)(ws + o_qb);
+        a.N = c->N;
+        a.tiles = tiles;
+        a.row_offset = c->row_offset;
+        a.nqg = nqg;
+        const int64_t min_len = tiles / nslices;  // shortest slice, in tiles
+        int ss = (int)(min_len / 8);
+        if (ss > 32) ss = 32;
+        if (ss < 1) ss = 1;
+        a.ss = ss;
+        a.maxima = (float*)(ws + o_max);
+        a.tau = (const float*)(ws + o_tau);
+        a.cnt = (int*)(ws + o_cnt);
+        a.cand = (uint64_t*)(ws + o_cand);
+        const int M = nslices * 2 * (TR / 32);
+        // aim at ~max(384, 6k) rows above tau; expected count ~ ss * M * -ln(1 - j/M)
+        int target = 6 * k > 384 ? 6 * k : 384;
+        int j = (target + ss - 1) / ss;
+        if (j < 16) j = 16;
+        if (j > M / 2) j = M / 2;
+
+#define HRS_SCAN(KS_, TR_)                                     \
+    case KS_:                                                  \
+        rc = launch_scan<KS_, TR_>(a, true, st);               \
+        if (rc) return rc;                                     \
+        hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt); \
+        rc = launch_scan<KS_, TR_>(a, false, st);              \
+        if (rc) return rc;                                     \
+        break;
+        switch (KS) {
+            HRS_SCAN(8, 64)
+            HRS_SCAN(16, 64)
+            HRS_SCAN(24, 64)
+            HRS_SCAN(32, 32)
+            default:
+                hrs_set_error("hrs_launch_mfma: no kernel for padded depth %d", Dpad);
+                return HRS_ERR_UNSUPPORTED;
+        }
+#undef HRS_SCAN
+        SelectArgs s;
+        s.C = c->C;
+        s.Q = Q;
+        s.D = c->D;
+        s.N = c->N;
+        s.row_offset = c->row_offset;
+        s.B = bc;
+        s.k = k;
+        s.cnt = a.cnt;
+        s.cand = a.cand;
+        s.tau = a.tau;
+        s.qn2 = (const double*)(ws + o_qn);
+        s.norm_stats = c->norm_stats;
+        s.eps_rel = MF_EPS_BASE + MF_EPS_PER_D * Dpad;
+        s.keys_out = keys_out;
+        s.qlist = qlist;
+        s.nflag = nflag;
+        s.stats = (long long*)ctx->stats_dev;
+        s.qbase = qbase;
+        if (space == HRS_SPACE_L2)
+            hipLaunchKernelGGL(k_select_rescore<HRS_SPACE_L2>, dim3(bc), dim3(256), 0, st, s);
+        else if (space == HRS_SPACE_COSINE)
+            hipLaunchKernelGGL(k_select_rescore<HRS_SPACE_COSINE>, dim3(bc), dim3(256), 0, st, s);
+        else
+            hipLaunchKernelGGL(k_select_rescore<HRS_SPACE_IP>, dim3(bc), dim3(256), 0, st, s);
+        HRS_CHECK_HIP(hipGetLastError());
+    }
+    // queries that could not be proven take the exact scan (device-side count; usually zero)
+    return hrs_launch_exact(ctx, c, Q, B, k, space, nullptr, qlist, nflag, keys_out, st);
+}

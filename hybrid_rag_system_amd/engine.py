@@ -1,0 +1,183 @@
+"""Host-side handles over the C ABI: one Engine per GPU, torch tensors as device memory.
+
+torch is plumbing here (allocation, streams, torch.distributed); every computation on the retrieval
+path is a HIP kernel of libhrs.so.  Nothing in this module computes on the CPU and nothing falls
+back to torch ops: a missing library or GPU raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Corpus:
+    """The embedding matrix of one shard, registered with the engine (keeps `matrix` alive)."""
+
+    def __init__(self, engine, matrix, row_offset=0):
+        if not (matrix.is_cuda and matrix.dtype == torch.float32 and matrix.dim() == 2 and matrix.is_contiguous()):
+            raise ValueError("corpus must be a contiguous fp32 [N, D] CUDA tensor")
+        self.engine = engine
+        self.matrix = matrix
+        self.n, self.dim = matrix.shape
+        self.row_offset = int(row_offset)
+        h = C.c_void_p()
+        N.check(
+            N.lib().hrs_corpus_register(engine._ctx, _ptr(matrix) if self.n else None, self.n, self.dim, self.row_offset, _stream(), C.byref(h)),
+            "hrs_corpus_register",
+        )
+        self._h = h
+
+    def norm_stats(self):
+        mn, mx = C.c_double(), C.c_double()
+        N.check(N.lib().hrs_corpus_stats(self.engine._ctx, self._h, _stream(), C.byref(mn), C.byref(mx)), "hrs_corpus_stats")
+        return mn.value, mx.value
+
+    def close(self):
+        if self._h is not None:
+            N.lib().hrs_corpus_release(self.engine._ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Postings:
+    """Forward CSR term lists of one shard (keeps both tensors alive)."""
+
+    def __init__(self, engine, doc_offs, term_ids, row_offset=0):
+        if not (doc_offs.is_cuda and doc_offs.dtype == torch.int64 and doc_offs.is_contiguous()):
+            raise ValueError("doc_offs must be a contiguous int64 CUDA tensor")
+        if not (term_ids.is_cuda and term_ids.dtype == torch.int32 and term_ids.is_contiguous()):
+            raise ValueError("term_ids must be a contiguous int32 CUDA tensor")
+        self.engine, self.doc_offs, self.term_ids = engine, doc_offs, term_ids
+        self.n = doc_offs.numel() - 1
+        self.row_offset = int(row_offset)
+        h = C.c_void_p()
+        N.check(N.lib().hrs_postings_register(engine._ctx, _ptr(doc_offs), _ptr(term_ids), self.n, self.row_offset, C.byref(h)), "hrs_postings_register")
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            N.lib().hrs_postings_release(self.engine._ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One hrs_ctx on one MI355X."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise N.HrsError("no GPU visible: hybrid_rag_system_amd runs on MI355X (gfx950) only and has no CPU path")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        N.check(N.lib().hrs_ctx_create(device, C.byref(h)), "hrs_ctx_create")
+        self._ctx = h
+
+    def close(self):
+        if self._ctx is not None:
+            N.lib().hrs_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    # ---- registration -------------------------------------------------------------------------
+    def corpus(self, matrix, row_offset=0):
+        return Corpus(self, matrix, row_offset)
+
+    def postings(self, doc_offs, term_ids, row_offset=0):
+        return Postings(self, doc_offs, term_ids, row_offset)
+
+    # ---- scoring -------------------------------------------------------------------------------
+    def score_topk(self, corpus, queries, k, space="l2", mask=None, mode="auto", want_keys=False):
+        """-> (dist fp32 [B,k], rows int64 [B,k][, keys uint64-as-int64 [B,k]]) on the GPU."""
+        if not (queries.is_cuda and queries.dtype == torch.float32 and queries.dim() == 2 and queries.is_contiguous()):
+            raise ValueError("queries must be a contiguous fp32 [B, D] CUDA tensor")
+        if queries.shape[1] != corpus.dim:
+            raise ValueError(f"query dim {queries.shape[1]} != corpus dim {corpus.dim}")
+        B = queries.shape[0]
+        dist = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        rows = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        keys = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        m = {"auto": N.MODE_AUTO, "exact": N.MODE_EXACT, "mfma": N.MODE_MFMA}[mode]
+        N.check(
+            N.lib().hrs_score_topk(self._ctx, corpus._h, _ptr(queries), B, k, N.SPACES[space], _ptr(mask), m, _ptr(keys), _ptr(dist), _ptr(rows), _stream()),
+            "hrs_score_topk",
+        )
+        return (dist, rows, keys) if want_keys else (dist, rows)
+
+    def score_stats(self):
+        out = (C.c_int64 * 3)()
+        N.check(N.lib().hrs_score_stats(self._ctx, _stream(), out), "hrs_score_stats")
+        return {"fallback_queries": out[0], "max_candidates": out[1], "overflow_queries": out[2]}
+
+    def keyword_counts(self, postings, q_terms, q_term_offs, cand_rows):
+        B, c = cand_rows.shape
+        counts = torch.empty((B, c), dtype=torch.int32, device=self.device)
+        N.check(
+            N.lib().hrs_keyword_counts(self._ctx, postings._h, _ptr(q_terms), _ptr(q_term_offs), _ptr(cand_rows), B, c, _ptr(counts), _stream()),
+            "hrs_keyword_counts",
+        )
+        return counts
+
+    def fuse_sort(self, dist, counts, q_term_offs, n, boost=0.3):
+        B, c = dist.shape
+        combined = torch.empty((B, n), dtype=torch.float64, device=self.device)
+        perm = torch.empty((B, n), dtype=torch.int32, device=self.device)
+        N.check(
+            N.lib().hrs_fuse_sort(self._ctx, _ptr(dist), _ptr(counts), _ptr(q_term_offs), B, c, float(boost), n, _ptr(combined), _ptr(perm), _stream()),
+            "hrs_fuse_sort",
+        )
+        return combined, perm
+
+    def merge_topk(self, keys, vals=None):
+        """keys int64(uint64 bits) [G,B,k] (+ vals int32 [G,B,k]) -> best k per query."""
+        G, B, k = keys.shape
+        out = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        ov = torch.empty((B, k), dtype=torch.int32, device=self.device) if vals is not None else None
+        N.check(N.lib().hrs_merge_topk(self._ctx, _ptr(keys), _ptr(vals), G, B, k, _ptr(out), _ptr(ov), _stream()), "hrs_merge_topk")
+        return (out, ov) if vals is not None else out
+
+    def unpack_keys(self, keys):
+        dist = torch.empty(keys.shape, dtype=torch.float32, device=self.device)
+        rows = torch.empty(keys.shape, dtype=torch.int64, device=self.device)
+        N.check(N.lib().hrs_unpack_keys(self._ctx, _ptr(keys), keys.numel(), _ptr(dist), _ptr(rows), _stream()), "hrs_unpack_keys")
+        return dist, rows
+
+    def hybrid_topk(self, corpus, postings, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
+        """One pass of the hybrid path for a query batch (scripts/chromadb_helper.py:275-325 batched):
+        top-2n by distance -> keyword presence counts on those 2n rows -> fused score, stable order,
+        first n.  Returns dict of GPU tensors (rows/dist of the n kept, combined, counts)."""
+        c = 2 * n
+        dist, rows = self.score_topk(corpus, queries, c, space=space, mode=mode)
+        counts = self.keyword_counts(postings, q_terms, q_term_offs, rows)
+        combined, perm = self.fuse_sort(dist, counts, q_term_offs, n, boost)
+        return {"cand_dist": dist, "cand_rows": rows, "cand_counts": counts, "combined": combined, "perm": perm}
+
+    # ---- synthetic inputs ----------------------------------------------------------------------
+    def synth_rows(self, seed, row0, nrows, dim, normalize=True, out=None):
+        if out is None:
+            out = torch.empty((nrows, dim), dtype=torch.float32, device=self.device)
+        N.check(N.lib().hrs_synth_rows(self._ctx, seed, row0, nrows, dim, int(normalize), _ptr(out), _stream()), "hrs_synth_rows")
+        return out
+
+    def synth_postings(self, seed, row0, nrows, cdf, L):
+        out = torch.empty((nrows, L), dtype=torch.int32, device=self.device)
+        N.check(N.lib().hrs_synth_postings(self._ctx, seed, row0, nrows, cdf.numel(), L, _ptr(cdf), _ptr(out), _stream()), "hrs_synth_postings")
+        return out

@@ -1,0 +1,141 @@
+/*
+ * hrs.h -- C ABI of libhrs.so, the MI355X (gfx950) retrieval engine that sits behind the
+ * `chromadb_helper.py` embed / index / query surface of mxioi/hybrid-rag-system.
+ *
+ * The reference has no FFI of its own: its helper calls five methods of a ChromaDB collection
+ * object over HTTP.  Each entry point below names the reference call site it stands in for
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative hrs_status on failure; the message of
+ *     the last failure on the calling thread is read with hrs_last_error(); no C++ exception
+ *     crosses this boundary;
+ *   - all `*_dev` pointers are device pointers owned by the caller (torch-ROCm tensors: pass
+ *     data_ptr()); the library never frees them and keeps them only inside the handles that are
+ *     documented to (a registered corpus / postings / encoder keeps its inputs);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
+ *     work is enqueued on it and no entry point waits for the device unless it says so;
+ *   - one hrs_ctx per device; a ctx is not thread-safe, different ctxs are independent;
+ *   - result keys: uint64 = (orderable fp32 distance << 32) | global row, ascending = better;
+ *     HRS_PAD_KEY marks a missing entry (fewer rows than k).
+ */
+#ifndef HRS_H
+#define HRS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hrs_ctx hrs_ctx;
+typedef struct hrs_corpus hrs_corpus;
+typedef struct hrs_postings hrs_postings;
+typedef struct hrs_encoder hrs_encoder;
+
+enum hrs_status {
+    HRS_OK = 0,
+    HRS_ERR_ARG = -1,     /* bad argument (shape, range, null) */
+    HRS_ERR_HIP = -2,     /* a HIP runtime call failed */
+    HRS_ERR_NOMEM = -3,   /* device allocation failed */
+    HRS_ERR_UNSUPPORTED = -4
+};
+
+/* ChromaDB's `hnsw:space`; the reference creates its collection without one -> l2
+ * (scripts/chromadb_helper.py:82-86). */
+enum hrs_space { HRS_SPACE_L2 = 0, HRS_SPACE_COSINE = 1, HRS_SPACE_IP = 2 };
+
+/* How hrs_score_topk scores. AUTO picks EXACT for small batches / small or masked corpora and
+ * MFMA otherwise.  Both return identical results (MFMA re-scores its candidates exactly and
+ * falls back to EXACT for any query it cannot prove). */
+enum hrs_score_mode { HRS_MODE_AUTO = 0, HRS_MODE_EXACT = 1, HRS_MODE_MFMA = 2 };
+
+#define HRS_PAD_KEY 0xFFFFFFFFFFFFFFFFull
+#define HRS_MAX_K 128
+
+int hrs_version(void);
+/* Copies the calling thread's last error message (NUL terminated) into buf; returns its length. */
+int hrs_last_error(char* buf, size_t n);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Replaces chromadb.HttpClient(host, port) (scripts/chromadb_helper.py:74-76): the "server" is
+ * the GPU `device` of this process. */
+int hrs_ctx_create(int device, hrs_ctx** out);
+int hrs_ctx_destroy(hrs_ctx* ctx);
+
+/* ---- corpus: the collection's embedding matrix --------------------------------------------- */
+/* Stands in for the server side of collection.add(...) (scripts/chromadb_helper.py:397-401,
+ * 462-466, 474-478): C_dev is the fp32 [N, D] row-major embedding matrix of this shard, row i
+ * being global row row_offset + i.  The corpus handle keeps C_dev (caller must keep it alive)
+ * and owns a bf16 shadow copy plus row-norm statistics that it builds on `stream`.
+ * D must be a multiple of 4; N + row_offset must stay below 2^32. */
+int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, int D, int64_t row_offset, void* stream,
+                        hrs_corpus** out);
+int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* corpus);
+/* Waits for `stream`, then reports min/max squared row norm (0/0 for an empty corpus). */
+int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* corpus, void* stream, double* min_norm2, double* max_norm2);
+
+/* Replaces collection.query(query_embeddings, n_results) on the server
+ * (scripts/chromadb_helper.py:259-269 with n, 289-293 with 2n): exact top-k of every query row of
+ * Q_dev (fp32 [B, D]) over the corpus, ordered by (fp32 distance ascending, row ascending).
+ * row_mask_dev (nullable, uint8 [N]): rows with 0 are skipped -- the `where` filter
+ * (scripts/chromadb_helper.py:265-266); a mask forces EXACT mode.
+ * Outputs (each nullable): keys_dev uint64 [B, k]; dist_dev fp32 [B, k] (+inf when missing);
+ * rows_dev int64 [B, k] global rows (-1 when missing).  1 <= k <= HRS_MAX_K. */
+int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
+                   const uint8_t* row_mask_dev, int mode, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev,
+                   void* stream);
+
+/* Counters of the last MFMA-mode call on this ctx, valid after the stream has been waited for:
+ * out[0] = queries that took the exact fallback, out[1] = largest candidate count of a query,
+ * out[2] = queries whose candidate list overflowed. Waits for `stream`. */
+int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]);
+
+/* ---- keyword side -------------------------------------------------------------------------- */
+/* Forward CSR postings of this shard: the term ids of row i are
+ * term_ids_dev[doc_offs_dev[i] .. doc_offs_dev[i+1]).  The handle keeps both pointers. */
+int hrs_postings_register(hrs_ctx* ctx, const int64_t* doc_offs_dev, const int32_t* term_ids_dev, int64_t N,
+                          int64_t row_offset, hrs_postings** out);
+int hrs_postings_release(hrs_ctx* ctx, hrs_postings* p);
+
+/* Replaces the numerator of calculate_keyword_score (scripts/chromadb_helper.py:352-359) with
+ * "keyword in document" read as "term id in the row's term list": counts_dev[b][j] = how many of
+ * query b's terms q_terms_dev[q_term_offs_dev[b] .. q_term_offs_dev[b+1]) occur in candidate row
+ * cand_rows_dev[b][j] (global row; rows < 0 or outside this shard count 0). */
+int hrs_keyword_counts(hrs_ctx* ctx, hrs_postings* p, const int32_t* q_terms_dev, const int32_t* q_term_offs_dev,
+                       const int64_t* cand_rows_dev, int B, int c, int32_t* counts_dev, void* stream);
+
+/* Replaces the scoring loop, sort and cut of hybrid_query (scripts/chromadb_helper.py:302-325),
+ * in Python-float (fp64) arithmetic: sem = max(0, 1 - dist), kw = count / n_terms (0 without
+ * keywords), combined = sem * (1 - boost) + kw * boost; stable sort by combined descending; first
+ * n kept.  dist_dev fp32 [B, c] ascending per query, +inf = missing candidate.  Outputs:
+ * combined_dev fp64 [B, n] (-1 when missing), perm_dev int32 [B, n] index into the candidate list
+ * (-1 when missing).  c <= 2 * HRS_MAX_K. */
+int hrs_fuse_sort(hrs_ctx* ctx, const float* dist_dev, const int32_t* counts_dev, const int32_t* q_term_offs_dev,
+                  int B, int c, double boost, int n, double* combined_dev, int32_t* perm_dev, void* stream);
+
+/* ---- cross-shard merge (no counterpart in the single-process reference) -------------------- */
+/* keys_dev uint64 [G, B, k]: per-shard results gathered from G ranks (all-gather over RCCL is done
+ * by the caller).  vals_dev (nullable) int32 [G, B, k] rides along (per-candidate keyword counts).
+ * Writes the best k of each query's G*k keys (and their vals).  G * k <= 2048. */
+int hrs_merge_topk(hrs_ctx* ctx, const uint64_t* keys_dev, const int32_t* vals_dev, int G, int B, int k,
+                   uint64_t* out_keys_dev, int32_t* out_vals_dev, void* stream);
+/* keys -> (fp32 distance, int64 row); either output nullable. */
+int hrs_unpack_keys(hrs_ctx* ctx, const uint64_t* keys_dev, int64_t n, float* dist_dev, int64_t* rows_dev,
+                    void* stream);
+
+/* ---- synthetic inputs for benchmarks and tests --------------------------------------------- */
+/* Rows row0 .. row0+nrows-1 of the i.i.d. N(0,1) matrix keyed (seed, row, column), L2-normalised
+ * when normalize != 0; any shard of any size reproduces the same rows. */
+int hrs_synth_rows(hrs_ctx* ctx, uint64_t seed, int64_t row0, int64_t nrows, int D, int normalize, float* out_dev,
+                   void* stream);
+/* L distinct ascending term ids per row, drawn by inverse CDF from cdf_dev (fp32 [V], ascending,
+ * last = 1) keyed (seed, row, draw); out_dev int32 [nrows, L]. */
+int hrs_synth_postings(hrs_ctx* ctx, uint64_t seed, int64_t row0, int64_t nrows, int V, int L, const float* cdf_dev,
+                       int32_t* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRS_H */

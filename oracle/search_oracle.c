@@ -1,0 +1,222 @@
+/*
+ * search_oracle.c -- CPU oracle for everything below the reference's
+ * `collection.query(...)` seam.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py):
+ * the shipped library never links or loads this file.
+ *
+ * What it restates
+ * ----------------
+ * The reference (scripts/chromadb_helper.py:259-269 and 289-293) hands one query
+ * embedding to a ChromaDB server and gets back the n nearest rows by ascending
+ * distance; the collection is created without an `hnsw:space` key
+ * (scripts/chromadb_helper.py:82-86), so the space is ChromaDB's default, squared L2.
+ * ChromaDB (requirements.txt:3, `chromadb>=0.4.0`, unpinned) is neither vendored in
+ * the reference nor installed in the build container, and the reference holds no
+ * test vectors for it: PARITY UNPINNED against ChromaDB itself.  The semantics below
+ * are the ones this build defines and the HIP path is held to, bit for bit:
+ *
+ *   distance (fp64, from fp32 inputs, index order i = 0..D-1, one rounding per step):
+ *     l2     : acc = fma(q_i - c_i, q_i - c_i, acc)          (the hnswlib L2Sqr sum)
+ *     ip     : 1 - dot,      dot: acc = fma(q_i, c_i, acc)
+ *     cosine : 1 - dot / (sqrt(|q|^2) * sqrt(|c|^2)); 1 when either norm is 0
+ *   reported distance = that fp64 value rounded once to fp32 (ChromaDB returns fp32)
+ *   total order       = (reported fp32 distance ascending, row index ascending)
+ *
+ * The hybrid re-rank follows scripts/chromadb_helper.py:296-325 with the keyword
+ * presence test (scripts/chromadb_helper.py:352-359) taken over integer term ids:
+ * "keyword in document" <=> "term id in the document's term list".
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { SPACE_L2 = 0, SPACE_COSINE = 1, SPACE_IP = 2 };
+
+static inline uint32_t f32_orderable(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+static inline float orderable_f32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* Exact distance in fp64; every step is a single correctly rounded IEEE operation. */
+double hrs_oracle_dist64(const float* q, const float* c, int D, int space) {
+    double acc = 0.0;
+    if (space == SPACE_L2) {
+        for (int i = 0; i < D; ++i) {
+            double d = (double)q[i] - (double)c[i];
+            acc = fma(d, d, acc);
+        }
+        return acc;
+    }
+    for (int i = 0; i < D; ++i) acc = fma((double)q[i], (double)c[i], acc);
+    if (space == SPACE_IP) return 1.0 - acc;
+    double nq = 0.0, nc = 0.0;
+    for (int i = 0; i < D; ++i) nq = fma((double)q[i], (double)q[i], nq);
+    for (int i = 0; i < D; ++i) nc = fma((double)c[i], (double)c[i], nc);
+    if (nq == 0.0 || nc == 0.0) return 1.0;
+    return 1.0 - acc / (sqrt(nq) * sqrt(nc));
+}
+
+/* key = (orderable fp32 distance << 32) | row : ascending key order == the total order. */
+uint64_t hrs_oracle_key(const float* q, const float* c, int D, int space, uint32_t row) {
+    float d32 = (float)hrs_oracle_dist64(q, c, D, space);
+    return ((uint64_t)f32_orderable(d32) << 32) | row;
+}
+
+static void insert_key(uint64_t* best, int k, uint64_t key) {
+    /* best[] ascending, length k, best[k-1] is the worst kept */
+    if (key >= best[k - 1]) return;
+    int j = k - 1;
+    while (j > 0 && best[j - 1] > key) {
+        best[j] = best[j - 1];
+        --j;
+    }
+    best[j] = key;
+}
+
+/*
+ * Exact top-k of every query over rows [0, N) (row ids reported as row_offset + local).
+ * mask (may be NULL): rows with mask[row] == 0 are skipped (the `where` filter,
+ * scripts/chromadb_helper.py:265-266).  out_keys[B][k], padded with UINT64_MAX.
+ */
+void hrs_oracle_topk(const float* Q, const float* C, int64_t N, int D, int B, int k, int space,
+                     int64_t row_offset, const uint8_t* mask, uint64_t* out_keys) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        uint64_t* best = out_keys + (size_t)b * k;
+        for (int j = 0; j < k; ++j) best[j] = UINT64_MAX;
+        const float* q = Q + (size_t)b * D;
+        for (int64_t r = 0; r < N; ++r) {
+            if (mask && !mask[r]) continue;
+            insert_key(best, k, hrs_oracle_key(q, C + (size_t)r * D, D, space, (uint32_t)(row_offset + r)));
+        }
+    }
+}
+
+/* Same result, parallel over rows instead of queries (for B smaller than the core count). */
+void hrs_oracle_topk_rows(const float* Q, const float* C, int64_t N, int D, int B, int k, int space,
+                          int64_t row_offset, const uint8_t* mask, uint64_t* out_keys) {
+    for (int b = 0; b < B; ++b) {
+        uint64_t* best = out_keys + (size_t)b * k;
+        for (int j = 0; j < k; ++j) best[j] = UINT64_MAX;
+        const float* q = Q + (size_t)b * D;
+#pragma omp parallel
+        {
+            uint64_t* mine = (uint64_t*)malloc(sizeof(uint64_t) * k);
+            for (int j = 0; j < k; ++j) mine[j] = UINT64_MAX;
+#pragma omp for schedule(static)
+            for (int64_t r = 0; r < N; ++r) {
+                if (mask && !mask[r]) continue;
+                insert_key(mine, k, hrs_oracle_key(q, C + (size_t)r * D, D, space, (uint32_t)(row_offset + r)));
+            }
+#pragma omp critical
+            for (int j = 0; j < k; ++j) insert_key(best, k, mine[j]);
+            free(mine);
+        }
+    }
+}
+
+void hrs_oracle_unpack(const uint64_t* keys, int64_t n, float* dist, int64_t* rows) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (keys[i] == UINT64_MAX) {
+            dist[i] = INFINITY;
+            rows[i] = -1;
+        } else {
+            dist[i] = orderable_f32((uint32_t)(keys[i] >> 32));
+            rows[i] = (int64_t)(keys[i] & 0xFFFFFFFFu);
+        }
+    }
+}
+
+/* Union of G per-shard lists [G][B][k] -> best k per query (cross-shard merge). */
+void hrs_oracle_merge(const uint64_t* keys, int G, int B, int k, uint64_t* out) {
+    for (int b = 0; b < B; ++b) {
+        uint64_t* best = out + (size_t)b * k;
+        for (int j = 0; j < k; ++j) best[j] = UINT64_MAX;
+        for (int g = 0; g < G; ++g)
+            for (int j = 0; j < k; ++j) insert_key(best, k, keys[((size_t)g * B + b) * k + j]);
+    }
+}
+
+/*
+ * Keyword presence counts over a forward CSR (doc_offs[row]..doc_offs[row+1] into term_ids).
+ * counts[b][j] = number of the query's terms present in candidate row rows[b][j]; 0 for rows < 0.
+ * Follows scripts/chromadb_helper.py:358 with "kw in doc_lower" read as "term id in the doc's list".
+ */
+void hrs_oracle_keyword_counts(const int64_t* doc_offs, const int32_t* term_ids, const int32_t* q_term_offs,
+                               const int32_t* q_terms, const int64_t* rows, int B, int c, int64_t row_offset,
+                               int32_t* counts) {
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < c; ++j) {
+            int64_t r = rows[(size_t)b * c + j];
+            int32_t n = 0;
+            if (r >= 0) {
+                r -= row_offset;
+                for (int32_t t = q_term_offs[b]; t < q_term_offs[b + 1]; ++t)
+                    for (int64_t p = doc_offs[r]; p < doc_offs[r + 1]; ++p)
+                        if (term_ids[p] == q_terms[t]) {
+                            ++n;
+                            break;
+                        }
+            }
+            counts[(size_t)b * c + j] = n;
+        }
+}
+
+/*
+ * Fusion and final order, scripts/chromadb_helper.py:302-325, in Python-float (fp64) arithmetic:
+ *   sem  = max(0, 1 - d)            d = the reported fp32 distance widened to fp64
+ *   kw   = count / n_terms          0.0 when the query has no keywords
+ *   comb = sem * (1 - boost) + kw * boost     (two products and one sum, each rounded)
+ * stable sort by comb descending, first n kept.  nvalid[b] = candidates the query really has.
+ * perm[b][i] = index into the candidate list (-1 past the end), combined[b][i] = its score.
+ */
+void hrs_oracle_fuse_sort(const float* dist, const int32_t* counts, const int32_t* n_terms, const int32_t* nvalid,
+                          int B, int c, double boost, int n, double* combined, int32_t* perm, double* sem_out,
+                          double* kw_out) {
+    double* comb = (double*)malloc(sizeof(double) * c);
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * c);
+    for (int b = 0; b < B; ++b) {
+        int nv = nvalid ? nvalid[b] : c;
+        for (int j = 0; j < nv; ++j) {
+            double d = (double)dist[(size_t)b * c + j];
+            double sem = 1.0 - d;
+            if (!(sem > 0.0)) sem = 0.0;
+            double kw = n_terms[b] > 0 ? (double)counts[(size_t)b * c + j] / (double)n_terms[b] : 0.0;
+            double w = 1.0 - boost;
+            volatile double p1 = sem * w;
+            volatile double p2 = kw * boost;
+            comb[j] = p1 + p2;
+            idx[j] = j;
+            if (sem_out) sem_out[(size_t)b * c + j] = sem;
+            if (kw_out) kw_out[(size_t)b * c + j] = kw;
+        }
+        for (int i = 1; i < nv; ++i) { /* stable insertion sort, descending */
+            double v = comb[i];
+            int32_t vi = idx[i];
+            int j = i;
+            while (j > 0 && comb[j - 1] < v) {
+                comb[j] = comb[j - 1];
+                idx[j] = idx[j - 1];
+                --j;
+            }
+            comb[j] = v;
+            idx[j] = vi;
+        }
+        for (int i = 0; i < n; ++i) {
+            combined[(size_t)b * n + i] = i < nv ? comb[i] : -1.0;
+            perm[(size_t)b * n + i] = i < nv ? idx[i] : -1;
+        }
+    }
+    free(comb);
+    free(idx);
+}

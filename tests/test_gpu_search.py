@@ -1,0 +1,254 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import search_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from hybrid_rag_system_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def _keys(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("n,d,b,k", [(20037, 384, 5, 10), (1000, 100, 3, 7), (4099, 1024, 2, 100), (63, 384, 1, 10)])
+def test_exact_scan_bit_exact(eng, space, n, d, b, k):
+    rng = np.random.default_rng(n + d)
+    C = _unit(rng, n, d)
+    if space != "l2":
+        C *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    C[n // 2] = C[3]  # exact duplicates: tie broken by row
+    C[n - 1] = C[3]
+    Q = _unit(rng, b, d)
+    Q[0] = C[3]
+    want = so.topk_keys(Q, C, k, space)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    dist, rows, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="exact", want_keys=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_keys(keys), want)
+    wd, wr = so.unpack(want)
+    assert np.array_equal(rows.cpu().numpy(), wr)
+    assert np.array_equal(dist.cpu().numpy(), wd)
+    corpus.close()
+
+
+def test_exact_fewer_rows_than_k_and_offset(eng):
+    rng = np.random.default_rng(5)
+    C = _unit(rng, 6, 384)
+    Q = _unit(rng, 2, 384)
+    want = so.topk_keys(Q, C, 10, "l2", row_offset=1000)
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), row_offset=1000)
+    dist, rows, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), 10, want_keys=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_keys(keys), want)
+    assert (rows.cpu().numpy()[:, 6:] == -1).all() and np.isinf(dist.cpu().numpy()[:, 6:]).all()
+    assert rows.cpu().numpy()[:, :6].min() >= 1000
+    corpus.close()
+
+
+def test_exact_mask(eng):
+    rng = np.random.default_rng(6)
+    C = _unit(rng, 5000, 384)
+    Q = _unit(rng, 4, 384)
+    mask = (rng.random(5000) < 0.3).astype(np.uint8)
+    want = so.topk_keys(Q, C, 10, "l2", mask=mask)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), 10, mask=torch.from_numpy(mask).cuda(), want_keys=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_keys(keys), want)
+    corpus.close()
+
+
+def test_empty_corpus(eng):
+    corpus = eng.corpus(torch.empty((0, 384), dtype=torch.float32, device="cuda"))
+    dist, rows = eng.score_topk(corpus, torch.zeros((2, 384), device="cuda"), 5)
+    torch.cuda.synchronize()
+    assert (rows.cpu().numpy() == -1).all()
+    corpus.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+def test_mfma_scan_bit_exact(eng, space):
+    """Matrix-core path: same keys as the exact oracle (ids, order and fp32 distances)."""
+    rng = np.random.default_rng(11)
+    n, d, b, k = 150_001, 384, 300, 20
+    C = _unit(rng, n, d)
+    Q = _unit(rng, b, d)
+    # planted near-duplicates (semantic score > 0 so the clamp is exercised later) and exact duplicates
+    for j in range(0, 40):
+        Q[j] = C[j * 997] + 0.05 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+        Q[j] /= np.linalg.norm(Q[j])
+    C[77777] = C[0]
+    C[150_000] = C[0]
+    want = so.topk_keys(Q, C, k, space)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    dist, rows, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    got = _keys(keys)
+    assert np.array_equal(got, want), f"mismatching queries: {np.nonzero((got != want).any(1))[0][:10]} stats={st}"
+    assert st["fallback_queries"] <= 3, st
+    assert st["overflow_queries"] == 0 and st["max_candidates"] < 4096, st
+    corpus.close()
+
+
+def test_mfma_fallback_on_heavy_ties(eng):
+    """More exact duplicates of the best row than the re-score window: the proof fails and the
+    query is answered by the exact scan, still bit-exact."""
+    rng = np.random.default_rng(12)
+    n, d, b, k = 70_000, 128, 20, 10
+    C = _unit(rng, n, d)
+    C[1000:1400] = C[5]
+    Q = _unit(rng, b, d)
+    Q[3] = C[5]
+    want = so.topk_keys(Q, C, k, "l2")
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    assert np.array_equal(_keys(keys), want), st
+    assert st["fallback_queries"] >= 1
+    corpus.close()
+
+
+def _postings(rng, n, V, L):
+    terms = np.empty((n, L), np.int32)
+    for i in range(n):
+        terms[i] = np.sort(rng.choice(V, L, replace=False))
+    return np.arange(n + 1, dtype=np.int64) * L, terms.reshape(-1)
+
+
+def test_keyword_counts_fuse_merge(eng):
+    rng = np.random.default_rng(21)
+    n, V, L, B, c = 3000, 500, 24, 37, 20
+    offs, terms = _postings(rng, n, V, L)
+    # ragged term lists: drop a few terms of some rows
+    m = rng.integers(0, 9, B)  # 0..8 query terms, including queries without keywords
+    qoffs = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms = np.concatenate([rng.choice(V, mm, replace=False) for mm in m] + [np.empty(0, np.int64)]).astype(np.int32)
+    rows = rng.integers(0, n, (B, c)).astype(np.int64)
+    rows[5, 15:] = -1
+    want = so.keyword_counts(offs, terms, qoffs, qterms, rows)
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
+    dq = torch.from_numpy(qterms).cuda() if qterms.size else torch.zeros(1, dtype=torch.int32, device="cuda")
+    got = eng.keyword_counts(post, dq, torch.from_numpy(qoffs).cuda(), torch.from_numpy(rows).cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+    dist = np.sort(rng.uniform(0.0, 2.2, (B, c)).astype(np.float32), axis=1)
+    dist[1, :] = 0.75  # all tied: stable order must keep the candidate order
+    dist[2, 3:9] = dist[2, 3]
+    dist[5, 15:] = np.inf
+    nvalid = np.full(B, c, np.int32)
+    nvalid[5] = 15
+    for n_keep in (10, 20):
+        wc, wp, _, _ = so.fuse_sort(dist, want, np.diff(qoffs), n_keep, 0.3, nvalid)
+        gc, gp = eng.fuse_sort(torch.from_numpy(dist).cuda(), got, torch.from_numpy(qoffs).cuda(), n_keep, 0.3)
+        assert np.array_equal(gp.cpu().numpy(), wp)
+        assert np.array_equal(gc.cpu().numpy().view(np.uint64), wc.view(np.uint64))  # bit-exact fp64
+
+    G, k = 4, 20
+    keys = rng.integers(0, 2**62, (G, B, k)).astype(np.uint64)
+    keys.sort(axis=2)
+    keys[2, 7, 10:] = so.PAD_KEY
+    vals = rng.integers(0, 9, (G, B, k)).astype(np.int32)
+    wk = so.merge(keys)
+    gk, gv = eng.merge_topk(torch.from_numpy(keys.view(np.int64)).cuda(), torch.from_numpy(vals).cuda())
+    assert np.array_equal(_keys(gk), wk)
+    lookup = {int(kk): int(v) for kk, v in zip(keys.reshape(-1), vals.reshape(-1))}
+    gvn = gv.cpu().numpy()
+    for b in range(B):
+        for j in range(k):
+            assert gvn[b, j] == lookup[int(wk[b, j])]
+    post.close()
+
+
+def test_sharded_equals_unsharded(eng):
+    """Row-shard the corpus 1/2/4/8 ways on one GPU, merge per-shard top-k, compare with one shard."""
+    rng = np.random.default_rng(31)
+    n, d, b, k = 9001, 384, 6, 20
+    C = _unit(rng, n, d)
+    Q = _unit(rng, b, d)
+    want = so.topk_keys(Q, C, k, "l2")
+    dq = torch.from_numpy(Q).cuda()
+    for G in (1, 2, 4, 8):
+        bounds = [n * g // G for g in range(G + 1)]
+        parts, keep = [], []
+        for g in range(G):
+            shard = torch.from_numpy(C[bounds[g] : bounds[g + 1]]).cuda()
+            cp = eng.corpus(shard, row_offset=bounds[g])
+            keep.append(cp)
+            parts.append(eng.score_topk(cp, dq, k, want_keys=True)[2])
+        merged = eng.merge_topk(torch.stack(parts))
+        torch.cuda.synchronize()
+        assert np.array_equal(_keys(merged), want), G
+        for cp in keep:
+            cp.close()
+
+
+def test_hybrid_pipeline_vs_oracle(eng):
+    rng = np.random.default_rng(41)
+    n, d, B, n_keep, V, L = 120_000, 384, 260, 10, 2000, 32
+    C = _unit(rng, n, d)
+    Q = _unit(rng, B, d)
+    for j in range(0, 60):
+        Q[j] = C[j * 1999] + 0.3 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+        Q[j] /= np.linalg.norm(Q[j])
+    terms = np.sort(rng.integers(0, V, (n, L)).astype(np.int32), axis=1)  # duplicates allowed inside a row
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    m = rng.integers(1, 9, B)
+    qoffs = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms = np.concatenate([rng.choice(V, mm, replace=False) for mm in m]).astype(np.int32)
+    # oracle
+    wkeys = so.topk_keys(Q, C, 2 * n_keep, "l2")
+    wd, wr = so.unpack(wkeys)
+    wcnt = so.keyword_counts(offs, terms.reshape(-1), qoffs, qterms, wr)
+    wc, wp, _, _ = so.fuse_sort(wd, wcnt, np.diff(qoffs), n_keep, 0.3)
+    # GPU
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms.reshape(-1)).cuda())
+    out = eng.hybrid_topk(corpus, post, torch.from_numpy(Q).cuda(), torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), n_keep, mode="mfma")
+    torch.cuda.synchronize()
+    assert np.array_equal(out["cand_rows"].cpu().numpy(), wr)
+    assert np.array_equal(out["cand_dist"].cpu().numpy(), wd)
+    assert np.array_equal(out["cand_counts"].cpu().numpy(), wcnt)
+    assert np.array_equal(out["perm"].cpu().numpy(), wp)
+    assert np.array_equal(out["combined"].cpu().numpy().view(np.uint64), wc.view(np.uint64))
+    assert (wc[:60, 0] > 0.3).any()  # the clamp max(0, 1-d) is not always active
+    corpus.close()
+    post.close()
+
+
+def test_synth_rows_shard_invariant(eng):
+    a = eng.synth_rows(1234, 0, 1000, 384)
+    b = eng.synth_rows(1234, 400, 300, 384)
+    torch.cuda.synchronize()
+    assert torch.equal(a[400:700], b)
+    nrm = a.norm(dim=1)
+    assert (nrm - 1).abs().max() < 1e-5
+    assert abs(float(a.mean())) < 1e-3 and abs(float(a.std()) - 1 / np.sqrt(384)) < 1e-3
+    cdf = torch.cumsum(1.0 / torch.arange(1, 5001, dtype=torch.float64), 0)
+    cdf = (cdf / cdf[-1]).float().cuda()
+    p = eng.synth_postings(777, 0, 2000, cdf, 96)
+    p2 = eng.synth_postings(777, 1000, 500, cdf, 96)
+    torch.cuda.synchronize()
+    assert torch.equal(p[1000:1500], p2)
+    pn = p.cpu().numpy()
+    assert (np.diff(pn, axis=1) > 0).all() and pn.min() >= 0 and pn.max() < 5000
+    assert (pn == 0).any(axis=1).mean() > 0.5  # the most popular term is in most rows (Zipf)
