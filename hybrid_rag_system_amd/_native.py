@@ -24,6 +24,8 @@ EXPORTS = [
     "hrs_corpus_stats",
     "hrs_score_topk",
     "hrs_score_stats",
+    "hrs_profile_enable",
+    "hrs_profile_read",
     "hrs_postings_register",
     "hrs_postings_release",
     "hrs_keyword_counts",
@@ -63,6 +65,8 @@ def lib():
             "hrs_corpus_stats": ([vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)], i32),
             "hrs_score_topk": ([vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], i32),
             "hrs_score_stats": ([vp, vp, C.POINTER(i64)], i32),
+            "hrs_profile_enable": ([vp, i32], i32),
+            "hrs_profile_read": ([vp, C.POINTER(dbl), C.POINTER(i64)], i32),
             "hrs_postings_register": ([vp, vp, vp, i64, i64, C.POINTER(vp)], i32),
             "hrs_postings_release": ([vp, vp], i32),
             "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),

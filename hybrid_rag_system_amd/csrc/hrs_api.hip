@@ -44,6 +44,45 @@ int hrs_ws_reserve(hrs_ctx* ctx, hrs_workspace* ws, size_t bytes) {
     return HRS_OK;
 }
 
+void hrs_prof_begin(hrs_ctx* ctx, hipStream_t st) {
+    if (!ctx->profile) return;
+    if (ctx->ev_used == ctx->ev_start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        ctx->ev_start.push_back(a);
+        ctx->ev_stop.push_back(b);
+    }
+    (void)hipEventRecord(ctx->ev_start[ctx->ev_used], st);
+}
+
+void hrs_prof_end(hrs_ctx* ctx, hipStream_t st) {
+    if (!ctx->profile || ctx->ev_used >= ctx->ev_stop.size()) return;
+    (void)hipEventRecord(ctx->ev_stop[ctx->ev_used], st);
+    ctx->ev_used++;
+}
+
+extern "C" int hrs_profile_enable(hrs_ctx* ctx, int on) {
+    HRS_REQUIRE(ctx, "hrs_profile_enable: null ctx");
+    ctx->profile = on != 0;
+    ctx->ev_used = 0;
+    return HRS_OK;
+}
+
+extern "C" int hrs_profile_read(hrs_ctx* ctx, double* total_ms, int64_t* launches) {
+    HRS_REQUIRE(ctx && total_ms && launches, "hrs_profile_read: null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        HRS_CHECK_HIP(hipEventSynchronize(ctx->ev_stop[i]));
+        float ms = 0.f;
+        HRS_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)ctx->ev_used;
+    ctx->ev_used = 0;
+    return HRS_OK;
+}
+
 extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
     HRS_REQUIRE(out != nullptr, "hrs_ctx_create: out is null");
     int ndev = 0;
@@ -79,6 +118,8 @@ extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
     if (ctx->ws_mfma.ptr) hipFree(ctx->ws_mfma.ptr);
     if (ctx->ws_keys.ptr) hipFree(ctx->ws_keys.ptr);
     if (ctx->stats_dev) hipFree(ctx->stats_dev);
+    for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);
     delete ctx;
     return HRS_OK;
 }

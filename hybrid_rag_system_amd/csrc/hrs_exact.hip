@@ -300,12 +300,14 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     a.tiles = tiles;
     const int bq = nq_dev ? 4 : B;
     if (c->N > 0) {
+        if (!nq_dev) hrs_prof_begin(ctx, st);
         if (space == HRS_SPACE_L2)
             rc = launch_exact_s<HRS_SPACE_L2>(a, grid, bq, st);
         else if (space == HRS_SPACE_COSINE)
             rc = launch_exact_s<HRS_SPACE_COSINE>(a, grid, bq, st);
         else
             rc = launch_exact_s<HRS_SPACE_IP>(a, grid, bq, st);
+        if (!nq_dev) hrs_prof_end(ctx, st);
         if (rc) return rc;
     } else {
         HRS_CHECK_HIP(hipMemsetAsync(p0, 0xFF, (size_t)B * grid * k * sizeof(uint64_t), st));

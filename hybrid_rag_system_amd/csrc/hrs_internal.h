@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/hrs.h"
 
 #define HRS_NUM_CU 256      // MI355X: 8 XCDs x 32 CUs
@@ -44,6 +46,10 @@ struct hrs_ctx {
     hrs_workspace ws_mfma;     // MFMA scan: bf16 queries, maxima, tau, counters, candidate lists
     hrs_workspace ws_keys;     // result keys when the caller asks only for distances / rows
     int64_t* stats_dev = nullptr;  // [8] counters of the last MFMA call
+    // optional kernel timing (hrs_profile_*): event pairs around the dominant scan kernel
+    bool profile = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used = 0;
 };
 
 struct hrs_corpus {
@@ -65,6 +71,9 @@ struct hrs_postings {
 };
 
 int hrs_ws_reserve(hrs_ctx* ctx, hrs_workspace* ws, size_t bytes);
+// Event pair around one launch of the dominant kernel when profiling is on (no-ops otherwise).
+void hrs_prof_begin(hrs_ctx* ctx, hipStream_t st);
+void hrs_prof_end(hrs_ctx* ctx, hipStream_t st);
 
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f32_orderable(float f) {

@@ -497,7 +497,9 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         rc = launch_scan<KS_, TR_>(a, true, st);               \
         if (rc) return rc;                                     \
         hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt); \
+        hrs_prof_begin(ctx, st);                               \
         rc = launch_scan<KS_, TR_>(a, false, st);              \
+        hrs_prof_end(ctx, st);                                 \
         if (rc) return rc;                                     \
         break;
         switch (KS) {

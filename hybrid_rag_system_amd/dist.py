@@ -1,0 +1,50 @@
+"""Row-sharding across the GPUs of one node: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The corpus rows (with their term lists) are split contiguously; queries are replicated.  Per query
+batch there is exactly one exchange step: an all-gather of every rank's local top-k' keys with the
+keyword counts of those candidates riding along (packed into one int64 tensor, so one collective).
+Every rank then runs the same deterministic merge and holds the same result.  The payload is tiny
+(B * k' * 16 bytes per rank), so the step is latency-bound; nothing is reduced and no ring is built.
+The reference has no counterpart: it is a single process (scripts/chromadb_helper.py:591-684).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world, rank):
+    """Contiguous row range [lo, hi) of `rank` out of `world` shards."""
+    return n_rows * rank // world, n_rows * (rank + 1) // world
+
+
+def pack_candidates(keys, counts):
+    """keys int64 [B,c] (uint64 bits) + counts int32 [B,c] -> int64 [B,c,2]."""
+    return torch.stack((keys, counts.to(torch.int64)), dim=-1).contiguous()
+
+
+def allgather_candidates(keys, counts, group=None):
+    """All-gather every rank's (keys, counts) -> keys int64 [G,B,c], counts int32 [G,B,c]."""
+    world = dist.get_world_size(group)
+    payload = pack_candidates(keys, counts)
+    out = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(out, payload, group=group)
+    return out[..., 0].contiguous(), out[..., 1].to(torch.int32).contiguous()
+
+
+class ShardedHybrid:
+    """Hybrid top-n over a row-sharded corpus; every rank returns the same merged result."""
+
+    def __init__(self, engine, corpus, postings, group=None):
+        self.engine, self.corpus, self.postings, self.group = engine, corpus, postings, group
+
+    def step(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
+        e = self.engine
+        c = 2 * n
+        # local top-2n of this shard is a superset of the shard's members of the global top-2n
+        _, rows, keys = e.score_topk(self.corpus, queries, c, space=space, mode=mode, want_keys=True)
+        counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            gk, gc = allgather_candidates(keys, counts, self.group)
+            keys, counts = e.merge_topk(gk, gc)
+        cand_dist, cand_rows = e.unpack_keys(keys)
+        combined, perm = e.fuse_sort(cand_dist, counts, q_term_offs, n, boost)
+        return {"cand_dist": cand_dist, "cand_rows": cand_rows, "cand_counts": counts, "combined": combined, "perm": perm}

@@ -127,6 +127,15 @@ class Engine:
         N.check(N.lib().hrs_score_stats(self._ctx, _stream(), out), "hrs_score_stats")
         return {"fallback_queries": out[0], "max_candidates": out[1], "overflow_queries": out[2]}
 
+    def profile(self, on=True):
+        N.check(N.lib().hrs_profile_enable(self._ctx, int(on)), "hrs_profile_enable")
+
+    def profile_read(self):
+        """-> (summed ms of the dominant scan kernel since the last read, number of launches)."""
+        ms, n = C.c_double(), C.c_int64()
+        N.check(N.lib().hrs_profile_read(self._ctx, C.byref(ms), C.byref(n)), "hrs_profile_read")
+        return ms.value, n.value
+
     def keyword_counts(self, postings, q_terms, q_term_offs, cand_rows):
         B, c = cand_rows.shape
         counts = torch.empty((B, c), dtype=torch.int32, device=self.device)

@@ -92,6 +92,13 @@ int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, 
  * out[2] = queries whose candidate list overflowed. Waits for `stream`. */
 int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]);
 
+/* Kernel timing for benchmarks: while enabled, every launch of the dominant scan kernel (the MFMA
+ * main pass in MFMA mode, the fp64 streaming scan in a direct EXACT-mode call) is bracketed by HIP
+ * events on the caller's stream.  hrs_profile_read waits for them, returns their summed duration
+ * and count, and resets the tally. */
+int hrs_profile_enable(hrs_ctx* ctx, int on);
+int hrs_profile_read(hrs_ctx* ctx, double* total_ms, int64_t* launches);
+
 /* ---- keyword side -------------------------------------------------------------------------- */
 /* Forward CSR postings of this shard: the term ids of row i are
  * term_ids_dev[doc_offs_dev[i] .. doc_offs_dev[i+1]).  The handle keeps both pointers. */
