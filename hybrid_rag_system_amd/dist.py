@@ -25,8 +25,10 @@ def allgather_candidates(keys, counts, group=None):
     """All-gather every rank's (keys, counts) -> keys int64 [G,B,c], counts int32 [G,B,c]."""
     world = dist.get_world_size(group)
     payload = pack_candidates(keys, counts)
-    out = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=payload.device)
-    dist.all_gather_into_tensor(out, payload, group=group)
+    # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [G, B, c, 2]
+    flat = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(flat, payload, group=group)
+    out = flat.view((world,) + tuple(payload.shape))
     return out[..., 0].contiguous(), out[..., 1].to(torch.int32).contiguous()
 
 
