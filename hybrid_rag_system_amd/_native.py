@@ -26,6 +26,9 @@ EXPORTS = [
     "hrs_score_stats",
     "hrs_profile_enable",
     "hrs_profile_read",
+    "hrs_encoder_load",
+    "hrs_encoder_release",
+    "hrs_encode",
     "hrs_postings_register",
     "hrs_postings_release",
     "hrs_keyword_counts",
@@ -35,6 +38,10 @@ EXPORTS = [
     "hrs_synth_rows",
     "hrs_synth_postings",
 ]
+
+
+class EncoderConfigC(C.Structure):
+    _fields_ = [("vocab", C.c_int), ("hidden", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("inter", C.c_int), ("max_pos", C.c_int), ("eps", C.c_float)]
 
 
 class HrsError(RuntimeError):
@@ -67,6 +74,9 @@ def lib():
             "hrs_score_stats": ([vp, vp, C.POINTER(i64)], i32),
             "hrs_profile_enable": ([vp, i32], i32),
             "hrs_profile_read": ([vp, C.POINTER(dbl), C.POINTER(i64)], i32),
+            "hrs_encoder_load": ([vp, vp, vp, vp, C.POINTER(vp)], i32),
+            "hrs_encoder_release": ([vp, vp], i32),
+            "hrs_encode": ([vp, vp, vp, vp, i32, i32, vp, vp], i32),
             "hrs_postings_register": ([vp, vp, vp, i64, i64, C.POINTER(vp)], i32),
             "hrs_postings_release": ([vp, vp], i32),
             "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),

@@ -1,0 +1,668 @@
+// MiniLM-class sentence encoder on the matrix cores (replaces the CPU torch forward that
+// sentence-transformers runs behind SentenceTransformerEmbeddingFunction, scripts/chromadb_helper.py:58-71).
+//
+//   k_embed_ln      word + position + type embedding gather, LayerNorm            -> x   bf16 [M, H]
+//   per layer:
+//   k_gemm<QKV>     x @ Wqkv^T + b; Q (pre-scaled) and K head-major, V in MFMA-fragment order
+//   k_attention     per (sequence, head): S = K Q^T in registers (S <= 256), masked softmax, O = P V
+//   k_gemm<RESID>   ctx @ Wo^T + b + x                                            -> pre-LN bf16
+//   k_layernorm                                                                   -> y   bf16
+//   k_gemm<GELU>    gelu(y @ Wi^T + b)                                            -> h   bf16 [M, I]
+//   k_gemm<RESID>   h @ Wd^T + b + y                                              -> pre-LN bf16
+//   k_layernorm                                                                   -> x
+//   k_pool_norm     masked mean over tokens, L2 normalise                         -> out fp32 [B, H]
+//
+// GEMM: C[M,N] = A[M,K] W[N,K]^T, bf16 in, fp32 accumulate (v_mfma_f32_32x32x16_bf16). Persistent
+// workgroups of 8 waves walk 256x192 output tiles; K advances in 64-wide stages that arrive in LDS
+// by LDS-DMA (double buffered, one barrier per stage, the next tile's first stage already in flight
+// during the epilogue). Both operands are K-contiguous, so either can be the MFMA's first operand:
+// token-major outputs use D = W x A^T (token on the lane: each lane stores 4 consecutive features),
+// the V output uses D = A x W^T (feature on the lane: each lane stores 4 consecutive tokens).
+// LDS rows are 128 B; 16-byte piece p of row r is stored at p ^ ((r >> 1) & 7) (permuted on the
+// DMA's source side), which makes the ds_read_b128 fragment reads conflict-free.
+#include "hrs_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define ENC_H 384
+#define ENC_HEADS 12
+#define ENC_DH 32
+#define G_BM 256
+#define G_BN 192
+#define G_BK 64
+#define G_STAGE_BYTES ((G_BM + G_BN) * G_BK * 2)  // 57344
+
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2 };
+
+struct GemmArgs {
+    const __bf16* A;     // [M, K]
+    const __bf16* W;     // [N, K]
+    const float* bias;   // [N]
+    const __bf16* resid; // [M, N] (EPI_RESID)
+    __bf16* C;           // [M, N] (EPI_RESID, EPI_GELU)
+    __bf16* q;           // EPI_QKV: [B][heads][S][32], pre-scaled
+    __bf16* k;           // EPI_QKV: [B][heads][S][32]
+    __bf16* vf;          // EPI_QKV: [B][heads][S/32][2][64][8]  (MFMA B-fragment order)
+    int M, N, K, S;
+    float qscale;
+};
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result)
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __expf(-z * z);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float erf_v = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_v);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 3, wn = wv >> 2;  // 4 waves along M (64 rows), 2 along N (96 columns)
+    const int h = lane >> 5, i = lane & 31;
+    const int ksteps = a.K / G_BK;
+    const int tiles_n = a.N / G_BN;
+    const int tiles = (a.M / G_BM) * tiles_n;
+    // blocks that share an XCD (blockIdx % 8) take neighbouring tiles: they reuse A rows / W columns in L2
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int my_tiles = bid < tiles ? (tiles - bid + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int stages = my_tiles * ksteps;
+    if (stages == 0) return;
+    const uint32_t lds0 = lds_addr_of(smem);
+
+    // DMA source offsets: this wave moves 7 of the 56 one-KiB pieces of a stage (32 for A, 24 for W)
+    int srcoff[7];
+    bool isA[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int piece = wv * 7 + j;
+        const bool pa = piece < 32;
+        const int r = (pa ? piece : piece - 32) * 8 + (lane >> 3);  // row inside the A / W tile
+        const int p = lane & 7;
+        isA[j] = pa;
+        srcoff[j] = (r * a.K + ((p ^ ((r >> 1) & 7)) << 3)) * 2;
+    }
+    auto issue = [&](int s, int buf) {
+        const int t = bid + (s / ksteps) * (int)gridDim.x;
+        const int kk = s % ksteps;
+        const int tm = t / tiles_n, tn = t % tiles_n;
+        const char* baseA = uniform_ptr(a.A + ((size_t)tm * G_BM * a.K + kk * G_BK));
+        const char* baseW = uniform_ptr(a.W + ((size_t)tn * G_BN * a.K + kk * G_BK));
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G_STAGE_BYTES + wv * 7 * 1024);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) glds16_asm(isA[j] ? baseA : baseW, srcoff[j], dst + j * 1024);
+    };
+
+    // fragment read offsets: k16-step ks of tile row i wants piece 2ks+h, stored at (2ks+h) ^ ((i>>1)&7)
+    int off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) off[ks] = i * 128 + (((2 * ks + h) ^ ((i >> 1) & 7)) << 4);
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+
+    f32x16 acc[2][3];
+    issue(0, 0);
+    bool prev_epilogue = false;
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        // retire this stage's DMA (older than the stores of a just-finished epilogue, if any)
+        if (prev_epilogue)
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < stages) issue(s + 1, buf ^ 1);
+        const int kk = s % ksteps;
+        if (kk == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        }
+        lds_cptr pa = (lds_cptr)(size_t)(lds0 + buf * G_STAGE_BYTES + wm * 64 * 128);
+        lds_cptr pw = (lds_cptr)(size_t)(lds0 + buf * G_STAGE_BYTES + G_BM * 128 + wn * 96 * 128);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fw[3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const __attribute__((address_space(3))) bf16x8*)(pa + mt * 4096 + off[ks]);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) fw[nt] = *(const __attribute__((address_space(3))) bf16x8*)(pw + nt * 4096 + off[ks]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    if (EPI == EPI_QKV) {
+                        // orientation is decided per wave below; both products are needed only for V
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+        }
+        prev_epilogue = false;
+        if (kk == ksteps - 1) {
+            prev_epilogue = true;
+            const int t = bid + (s / ksteps) * (int)gridDim.x;
+            const int tm = t / tiles_n, tn = t % tiles_n;
+            // D = W x A^T: lane <-> token (column), registers <-> features (rows):
+            //   feature = n0 + (r & 3) + 8 (r >> 2) + 4 h, token = m0 + i
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int token = tm * G_BM + wm * 64 + mt * 32 + i;
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    const int n0 = tn * G_BN + wn * 96 + nt * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int f = n0 + 8 * g + 4 * h;  // 4 consecutive features f .. f+3
+                        const float4 bv = *(const float4*)(a.bias + f);
+                        float v0 = acc[mt][nt][4 * g + 0] + bv.x, v1 = acc[mt][nt][4 * g + 1] + bv.y;
+                        float v2 = acc[mt][nt][4 * g + 2] + bv.z, v3 = acc[mt][nt][4 * g + 3] + bv.w;
+                        if (EPI == EPI_RESID) {
+                            const bf16x4 rv = *(const bf16x4*)(a.resid + (size_t)token * a.N + f);
+                            v0 += (float)rv[0];
+                            v1 += (float)rv[1];
+                            v2 += (float)rv[2];
+                            v3 += (float)rv[3];
+                        }
+                        if (EPI == EPI_GELU) {
+                            v0 = gelu_erf(v0);
+                            v1 = gelu_erf(v1);
+                            v2 = gelu_erf(v2);
+                            v3 = gelu_erf(v3);
+                        }
+                        bf16x4 o;
+                        if (EPI == EPI_QKV) {
+                            const int which = f / ENC_H;          // 0 q, 1 k, 2 v (uniform per wave)
+                            const int hf = f % ENC_H;
+                            const int head = hf >> 5, d = hf & 31;  // d = 8g + 4h (+0..3)
+                            const int b = token / a.S, sp = token % a.S;
+                            if (which == 0) {
+                                o[0] = (__bf16)(v0 * a.qscale);
+                                o[1] = (__bf16)(v1 * a.qscale);
+                                o[2] = (__bf16)(v2 * a.qscale);
+                                o[3] = (__bf16)(v3 * a.qscale);
+                                *(bf16x4*)(a.q + (((size_t)b * ENC_HEADS + head) * a.S + sp) * ENC_DH + d) = o;
+                            } else if (which == 1) {
+                                o[0] = (__bf16)v0;
+                                o[1] = (__bf16)v1;
+                                o[2] = (__bf16)v2;
+                                o[3] = (__bf16)v3;
+                                *(bf16x4*)(a.k + (((size_t)b * ENC_HEADS + head) * a.S + sp) * ENC_DH + d) = o;
+                            } else {
+                                // V in the order the attention kernel's P.V product consumes it as B operand:
+                                // key = 32 kt + 16 s2 + 8 (e >> 2) + 4 hh + (e & 3), column = d
+                                //   -> vf[kt][s2][lane' = 32 hh + d][e]; this lane holds ONE key (sp) and 4 columns
+                                const int kt = sp >> 5, s2 = (sp >> 4) & 1, e = (((sp >> 3) & 1) << 2) | (sp & 3), hh = (sp >> 2) & 1;
+                                __bf16* vb = a.vf + (((size_t)b * ENC_HEADS + head) * (a.S >> 5) + kt) * (2 * 64 * 8) + s2 * 512 + hh * 256 + e;
+                                vb[(d + 0) * 8] = (__bf16)v0;
+                                vb[(d + 1) * 8] = (__bf16)v1;
+                                vb[(d + 2) * 8] = (__bf16)v2;
+                                vb[(d + 3) * 8] = (__bf16)v3;
+                            }
+                        } else {
+                            o[0] = (__bf16)v0;
+                            o[1] = (__bf16)v1;
+                            o[2] = (__bf16)v2;
+                            o[3] = (__bf16)v3;
+                            *(bf16x4*)(a.C + (size_t)token * a.N + f) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- attention -----------------------------------------------------------------------------------
+// One workgroup (4 waves) per (sequence, head); a wave owns 32-query tiles. With S <= 256 the whole
+// score row lives in registers: S^T = K Q^T puts the query on the lane, so the row maximum and sum
+// are in-lane reductions plus one exchange between lane halves; P (bf16) then feeds O = P V as the
+// first MFMA operand with no lane movement (the k order of that product is the accumulator's
+// register order, which is the order V was stored in by the QKV epilogue).
+struct AttnArgs {
+    const __bf16* q;   // [B][heads][S][32], scaled by log2(e)/sqrt(32)
+    const __bf16* k;   // [B][heads][S][32]
+    const __bf16* vf;  // [B][heads][S/32][2][64][8]
+    const int* lens;   // [B]
+    __bf16* ctx;       // [B*S][384]
+    int S;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    const int bh = blockIdx.x;
+    const int b = bh / ENC_HEADS, head = bh % ENC_HEADS;
+    const int S = NKT * 32;
+    const int len = a.lens[b];
+    const __bf16* qb = a.q + (size_t)bh * S * ENC_DH;
+    const __bf16* kb = a.k + (size_t)bh * S * ENC_DH;
+    const __bf16* vb = a.vf + (size_t)bh * S * ENC_DH;
+
+    // K fragments (first operand, rows = keys): lane (i, h), k-step ks -> K[32 kt + i][16 ks + 8 h ..]
+    bf16x8 kf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = *(const bf16x8*)(kb + (kt * 32 + i) * ENC_DH + ks * 16 + h * 8);
+
+    for (int qt = wv; qt < NKT; qt += 4) {
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + (qt * 32 + i) * ENC_DH + ks * 16 + h * 8);
+        f32x16 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], sc[kt], 0, 0, 0);
+        }
+        // sc[kt][r] = score(query qt*32 + i, key kt*32 + (r&3) + 8(r>>2) + 4h), in log2 units
+        float m = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = key < len ? sc[kt][r] : -1e30f;
+                sc[kt][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(sc[kt][r] - m);
+                sc[kt][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        // O = P V: first operand = P (registers 8 s2 .. 8 s2 + 7 of tile kt), second = V fragments
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)(sc[kt][8 * s2 + e] * inv);
+                const bf16x8 vfrag = *(const bf16x8*)(vb + ((kt * 2 + s2) * 64 + lane) * 8);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vfrag, o, 0, 0, 0);
+            }
+        // o[r] = O[query qt*32 + (r&3) + 8(r>>2) + 4h][column i]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            a.ctx[((size_t)b * S + qrow) * ENC_H + head * ENC_DH + i] = (__bf16)o[r];
+        }
+    }
+}
+
+// ---- row-wise kernels ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per token: 384 features = 6 per lane.
+__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, const float* __restrict__ word,
+                                                  const float* __restrict__ pos, const float* __restrict__ type0,
+                                                  const float* __restrict__ g, const float* __restrict__ bta, int M,
+                                                  int Mreal, int S, int vocab, float eps, __bf16* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= M) return;
+    int id = t < Mreal ? ids[t] : 0;
+    if (id < 0 || id >= vocab) id = 0;
+    const int sp = t % S;
+    float v[6];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = word[(size_t)id * ENC_H + c] + pos[(size_t)sp * ENC_H + c] + type0[c];
+        sum += v[j];
+    }
+    const float mean = wave_sum(sum) * (1.0f / ENC_H);
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float d = v[j] - mean;
+        var += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(var) * (1.0f / ENC_H) + eps);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int c = lane + 64 * j;
+        x[(size_t)t * ENC_H + c] = (__bf16)((v[j] - mean) * rstd * g[c] + bta[c]);
+    }
+}
+
+// LayerNorm of bf16 rows: lanes 0..47 hold 8 features each (16-byte accesses).
+__global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ in, const float* __restrict__ g,
+                                                   const float* __restrict__ bta, int M, float eps,
+                                                   __bf16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= M) return;
+    float v[8];
+    float sum = 0.f;
+    const bool on = lane < 48;
+    if (on) {
+        const bf16x8 r = *(const bf16x8*)(in + (size_t)t * ENC_H + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (float)r[j];
+            sum += v[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    const float mean = wave_sum(sum) * (1.0f / ENC_H);
+    float var = 0.f;
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[j] - mean;
+            var += d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(var) * (1.0f / ENC_H) + eps);
+    if (on) {
+        bf16x8 o;
+        const float4 g0 = *(const float4*)(g + lane * 8), g1 = *(const float4*)(g + lane * 8 + 4);
+        const float4 b0 = *(const float4*)(bta + lane * 8), b1 = *(const float4*)(bta + lane * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)((v[j] - mean) * rstd * gg[j] + bb[j]);
+        *(bf16x8*)(out + (size_t)t * ENC_H + lane * 8) = o;
+    }
+}
+
+// Masked mean over the sequence + L2 normalisation. One block of 384 threads per sequence.
+__global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x, const int* __restrict__ lens, int S,
+                                                   float* __restrict__ out) {
+    __shared__ float red[6];
+    const int b = blockIdx.x, c = threadIdx.x;
+    int len = lens[b];
+    if (len > S) len = S;
+    float s = 0.f;
+    for (int t = 0; t < len; ++t) s += (float)x[((size_t)b * S + t) * ENC_H + c];
+    const float denom = len > 0 ? (float)len : 1e-9f;
+    const float mean = s / denom;
+    float ss = wave_sum(mean * mean);
+    if ((c & 63) == 0) red[c >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tot += red[j];
+    const float nrm = fmaxf(sqrtf(tot), 1e-12f);
+    out[(size_t)b * ENC_H + c] = mean / nrm;
+}
+
+__global__ void k_to_bf16(const float* __restrict__ in, int64_t n, __bf16* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = (__bf16)in[idx];
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+struct hrs_encoder {
+    hrs_encoder_config cfg;
+    // fp32 tables / vectors (owned copies)
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    struct Layer {
+        __bf16 *wqkv = nullptr, *wo = nullptr, *wi = nullptr, *wd = nullptr;
+        float *bqkv = nullptr, *bo = nullptr, *bi = nullptr, *bd = nullptr;
+        float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+    } layer[16];
+    std::vector<void*> owned;
+    hrs_workspace ws;
+};
+
+static int dev_alloc(hrs_encoder* e, void** p, size_t bytes) {
+    hipError_t err = hipMalloc(p, bytes);
+    if (err != hipSuccess) {
+        hrs_set_error("encoder allocation of %zu bytes failed: %s", bytes, hipGetErrorString(err));
+        return HRS_ERR_NOMEM;
+    }
+    e->owned.push_back(*p);
+    return HRS_OK;
+}
+
+static int copy_f32(hrs_encoder* e, float** dst, const float* src_dev, size_t n, hipStream_t st) {
+    int rc = dev_alloc(e, (void**)dst, n * sizeof(float));
+    if (rc) return rc;
+    HRS_CHECK_HIP(hipMemcpyAsync(*dst, src_dev, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return HRS_OK;
+}
+
+static int conv_bf16(hrs_encoder* e, __bf16* dst, const float* src_dev, size_t n, hipStream_t st) {
+    (void)e;
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src_dev, (int64_t)n, dst);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+extern "C" int hrs_encoder_load(hrs_ctx* ctx, const hrs_encoder_config* cfg, const float* const* w, void* stream,
+                                hrs_encoder** out) {
+    HRS_REQUIRE(ctx && cfg && w && out, "hrs_encoder_load: null argument");
+    HRS_REQUIRE(cfg->hidden == ENC_H && cfg->heads == ENC_HEADS, "hrs_encoder_load: only hidden=384, heads=12 (MiniLM-L6/L12 geometry) is built");
+    HRS_REQUIRE(cfg->inter % G_BN == 0 && cfg->inter % G_BK == 0 && cfg->inter <= 3072, "hrs_encoder_load: intermediate size %d must be a multiple of 192", cfg->inter);
+    HRS_REQUIRE(cfg->layers >= 1 && cfg->layers <= 16, "hrs_encoder_load: layers=%d outside [1,16]", cfg->layers);
+    HRS_REQUIRE(cfg->vocab > 0 && cfg->max_pos >= 32, "hrs_encoder_load: bad vocabulary / position table size");
+    const int nt = 5 + 16 * cfg->layers;
+    for (int t = 0; t < nt; ++t) HRS_REQUIRE(w[t] != nullptr, "hrs_encoder_load: weight tensor %d is null", t);
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    hrs_encoder* e = new hrs_encoder();
+    e->cfg = *cfg;
+    const size_t H = ENC_H, I = cfg->inter;
+    int rc = 0;
+#define TRY(x)                          \
+    do {                                \
+        rc = (x);                       \
+        if (rc) goto fail;              \
+    } while (0)
+    TRY(copy_f32(e, &e->word, w[0], (size_t)cfg->vocab * H, st));
+    TRY(copy_f32(e, &e->pos, w[1], (size_t)cfg->max_pos * H, st));
+    TRY(copy_f32(e, &e->type0, w[2], H, st));
+    TRY(copy_f32(e, &e->emb_g, w[3], H, st));
+    TRY(copy_f32(e, &e->emb_b, w[4], H, st));
+    for (int l = 0; l < cfg->layers; ++l) {
+        const float* const* p = w + 5 + 16 * l;  // q_w q_b k_w k_b v_w v_b o_w o_b ln1_g ln1_b i_w i_b d_w d_b ln2_g ln2_b
+        hrs_encoder::Layer& L = e->layer[l];
+        TRY(dev_alloc(e, (void**)&L.wqkv, 3 * H * H * sizeof(__bf16)));
+        TRY(dev_alloc(e, (void**)&L.bqkv, 3 * H * sizeof(float)));
+        for (int j = 0; j < 3; ++j) {
+            TRY(conv_bf16(e, L.wqkv + j * H * H, p[2 * j], H * H, st));
+            if (hipMemcpyAsync(L.bqkv + j * H, p[2 * j + 1], H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                hrs_set_error("hrs_encoder_load: bias copy failed");
+                rc = HRS_ERR_HIP;
+                goto fail;
+            }
+        }
+        TRY(dev_alloc(e, (void**)&L.wo, H * H * sizeof(__bf16)));
+        TRY(conv_bf16(e, L.wo, p[6], H * H, st));
+        TRY(copy_f32(e, &L.bo, p[7], H, st));
+        TRY(copy_f32(e, &L.ln1g, p[8], H, st));
+        TRY(copy_f32(e, &L.ln1b, p[9], H, st));
+        TRY(dev_alloc(e, (void**)&L.wi, I * H * sizeof(__bf16)));
+        TRY(conv_bf16(e, L.wi, p[10], I * H, st));
+        TRY(copy_f32(e, &L.bi, p[11], I, st));
+        TRY(dev_alloc(e, (void**)&L.wd, H * I * sizeof(__bf16)));
+        TRY(conv_bf16(e, L.wd, p[12], H * I, st));
+        TRY(copy_f32(e, &L.bd, p[13], H, st));
+        TRY(copy_f32(e, &L.ln2g, p[14], H, st));
+        TRY(copy_f32(e, &L.ln2b, p[15], H, st));
+    }
+#undef TRY
+    *out = e;
+    return HRS_OK;
+fail:
+    for (void* p : e->owned) (void)hipFree(p);
+    delete e;
+    return rc;
+}
+
+extern "C" int hrs_encoder_release(hrs_ctx* ctx, hrs_encoder* e) {
+    if (!e) return HRS_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->owned) (void)hipFree(p);
+    if (e->ws.ptr) (void)hipFree(e->ws.ptr);
+    delete e;
+    return HRS_OK;
+}
+
+template <int EPI>
+static int launch_gemm(hrs_ctx* ctx, const GemmArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    const int lds = 2 * G_STAGE_BYTES;
+    if (!attr_set) {
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int tiles = (g.M / G_BM) * (g.N / G_BN);
+    int grid = ctx->num_cu & ~7;
+    if (grid < 8) grid = 8;
+    if (tiles < grid) grid = (tiles + 7) & ~7;
+    hipLaunchKernelGGL((k_gemm<EPI>), dim3(grid), dim3(512), lds, st, g);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+static int launch_attention(const AttnArgs& a, int B, hipStream_t st) {
+    const int nkt = a.S / 32;
+    const dim3 grid(B * ENC_HEADS), block(256);
+    switch (nkt) {
+        case 1: hipLaunchKernelGGL((k_attention<1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_attention<2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_attention<3>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_attention<4>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_attention<5>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attention<6>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_attention<7>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_attention<8>), grid, block, 0, st, a); break;
+        default: hrs_set_error("attention: sequence length %d not a multiple of 32 in [32, 256]", a.S); return HRS_ERR_ARG;
+    }
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S,
+                          float* out_dev, void* stream) {
+    HRS_REQUIRE(ctx && e && ids_dev && lens_dev && out_dev, "hrs_encode: null argument");
+    HRS_REQUIRE(B >= 1, "hrs_encode: B=%d < 1", B);
+    HRS_REQUIRE(S >= 32 && S <= 256 && S % 32 == 0 && S <= e->cfg.max_pos, "hrs_encode: S=%d must be a multiple of 32 in [32, 256]", S);
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H = ENC_H, I = e->cfg.inter;
+    const int Mreal = B * S;
+    // whole sequences up to a multiple of 256 rows (8 sequences of 32 tokens = 256)
+    const int Bpad = (B + 7) & ~7;
+    const int M = Bpad * S;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_x = carve((size_t)M * H * 2), o_y = carve((size_t)M * H * 2), o_pre = carve((size_t)M * H * 2);
+    const size_t o_ctx = carve((size_t)M * H * 2), o_q = carve((size_t)M * H * 2), o_k = carve((size_t)M * H * 2);
+    const size_t o_v = carve((size_t)M * H * 2), o_h = carve((size_t)M * I * 2), o_len = carve((size_t)Bpad * 4);
+    int rc = hrs_ws_reserve(ctx, &e->ws, off);
+    if (rc) return rc;
+    char* ws = (char*)e->ws.ptr;
+    __bf16 *x = (__bf16*)(ws + o_x), *y = (__bf16*)(ws + o_y), *pre = (__bf16*)(ws + o_pre), *cx = (__bf16*)(ws + o_ctx);
+    __bf16 *q = (__bf16*)(ws + o_q), *k = (__bf16*)(ws + o_k), *vf = (__bf16*)(ws + o_v), *hbuf = (__bf16*)(ws + o_h);
+    int* lens = (int*)(ws + o_len);
+    HRS_CHECK_HIP(hipMemsetAsync(lens, 0, (size_t)Bpad * 4, st));
+    HRS_CHECK_HIP(hipMemcpyAsync(lens, lens_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_embed_ln, dim3((M + 3) / 4), dim3(256), 0, st, ids_dev, e->word, e->pos, e->type0, e->emb_g,
+                       e->emb_b, M, Mreal, S, e->cfg.vocab, e->cfg.eps, x);
+    for (int l = 0; l < e->cfg.layers; ++l) {
+        const hrs_encoder::Layer& L = e->layer[l];
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = M;
+        g.S = S;
+        g.A = x;
+        g.W = L.wqkv;
+        g.bias = L.bqkv;
+        g.N = 3 * H;
+        g.K = H;
+        g.q = q;
+        g.k = k;
+        g.vf = vf;
+        g.qscale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e): softmax in base 2
+        if ((rc = launch_gemm<EPI_QKV>(ctx, g, st))) return rc;
+        AttnArgs at;
+        at.q = q;
+        at.k = k;
+        at.vf = vf;
+        at.lens = lens;
+        at.ctx = cx;
+        at.S = S;
+        if ((rc = launch_attention(at, Bpad, st))) return rc;
+        memset(&g, 0, sizeof(g));
+        g.M = M;
+        g.S = S;
+        g.A = cx;
+        g.W = L.wo;
+        g.bias = L.bo;
+        g.resid = x;
+        g.C = pre;
+        g.N = H;
+        g.K = H;
+        if ((rc = launch_gemm<EPI_RESID>(ctx, g, st))) return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, L.ln1g, L.ln1b, M, e->cfg.eps, y);
+        g.A = y;
+        g.W = L.wi;
+        g.bias = L.bi;
+        g.resid = nullptr;
+        g.C = hbuf;
+        g.N = I;
+        g.K = H;
+        if ((rc = launch_gemm<EPI_GELU>(ctx, g, st))) return rc;
+        g.A = hbuf;
+        g.W = L.wd;
+        g.bias = L.bd;
+        g.resid = y;
+        g.C = pre;
+        g.N = H;
+        g.K = I;
+        if (l == e->cfg.layers - 1) hrs_prof_begin(ctx, st);
+        rc = launch_gemm<EPI_RESID>(ctx, g, st);
+        if (l == e->cfg.layers - 1) hrs_prof_end(ctx, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, L.ln2g, L.ln2b, M, e->cfg.eps, x);
+    }
+    hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(384), 0, st, x, lens, S, out_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}

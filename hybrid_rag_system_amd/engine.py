@@ -80,6 +80,48 @@ class Postings:
             pass
 
 
+class Encoder:
+    """MiniLM-class encoder resident on the GPU (owns its weight copies)."""
+
+    def __init__(self, engine, weights, cfg):
+        from .weights import tensor_specs
+
+        self.engine, self.cfg = engine, cfg
+        specs = tensor_specs(cfg)
+        dev = [torch.as_tensor(weights[name], dtype=torch.float32).contiguous().to(engine.device) for name, _ in specs]
+        for t, (name, shape) in zip(dev, specs):
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {shape}")
+        ptrs = (C.c_void_p * len(dev))(*[t.data_ptr() for t in dev])
+        c = N.EncoderConfigC(cfg.vocab, cfg.hidden, cfg.layers, cfg.heads, cfg.inter, cfg.max_pos, cfg.eps)
+        h = C.c_void_p()
+        N.check(N.lib().hrs_encoder_load(engine._ctx, C.byref(c), ptrs, _stream(), C.byref(h)), "hrs_encoder_load")
+        torch.cuda.current_stream().synchronize()  # the fp32 staging tensors may go now
+        self._h = h
+
+    def encode_ids(self, ids, lens):
+        """ids int32 [B,S] (S a multiple of 32, <= 256), lens int32 [B] -> fp32 [B, hidden] unit rows."""
+        if not (ids.is_cuda and ids.dtype == torch.int32 and ids.dim() == 2 and ids.is_contiguous()):
+            raise ValueError("ids must be a contiguous int32 [B, S] CUDA tensor")
+        if not (lens.is_cuda and lens.dtype == torch.int32 and lens.numel() == ids.shape[0]):
+            raise ValueError("lens must be an int32 [B] CUDA tensor")
+        B, S = ids.shape
+        out = torch.empty((B, self.cfg.hidden), dtype=torch.float32, device=self.engine.device)
+        N.check(N.lib().hrs_encode(self.engine._ctx, self._h, _ptr(ids), _ptr(lens), B, S, _ptr(out), _stream()), "hrs_encode")
+        return out
+
+    def close(self):
+        if self._h is not None:
+            N.lib().hrs_encoder_release(self.engine._ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One hrs_ctx on one MI355X."""
 
@@ -103,6 +145,9 @@ class Engine:
 
     def postings(self, doc_offs, term_ids, row_offset=0):
         return Postings(self, doc_offs, term_ids, row_offset)
+
+    def encoder(self, weights, cfg):
+        return Encoder(self, weights, cfg)
 
     # ---- scoring -------------------------------------------------------------------------------
     def score_topk(self, corpus, queries, k, space="l2", mask=None, mode="auto", want_keys=False):

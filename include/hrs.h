@@ -99,6 +99,28 @@ int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]);
 int hrs_profile_enable(hrs_ctx* ctx, int on);
 int hrs_profile_read(hrs_ctx* ctx, double* total_ms, int64_t* launches);
 
+/* ---- encoder ------------------------------------------------------------------------------- */
+/* Replaces the embedding function the reference builds with
+ * SentenceTransformerEmbeddingFunction(model_name="all-MiniLM-L6-v2") (scripts/chromadb_helper.py:58-71)
+ * and that ChromaDB calls inside collection.add / collection.query: BERT-style post-LN encoder,
+ * erf-GELU, masked mean pooling, L2 normalisation.  Built for hidden = 384, heads = 12. */
+typedef struct hrs_encoder_config {
+    int vocab, hidden, layers, heads, inter, max_pos;
+    float eps;
+} hrs_encoder_config;
+/* weights_dev: 5 + 16 * layers fp32 DEVICE tensors in this order: word_emb [vocab, H], pos_emb
+ * [max_pos, H], type_emb [2, H], emb_ln_gamma, emb_ln_beta, then per layer q_w [H,H], q_b, k_w, k_b,
+ * v_w, v_b, o_w [H,H], o_b, ln1_gamma, ln1_beta, i_w [I,H], i_b, d_w [H,I], d_b, ln2_gamma, ln2_beta
+ * (linear weights [out, in]).  The encoder owns bf16 / fp32 copies; the inputs may be freed once
+ * `stream` has been waited for. */
+int hrs_encoder_load(hrs_ctx* ctx, const hrs_encoder_config* cfg, const float* const* weights_dev, void* stream,
+                     hrs_encoder** out);
+int hrs_encoder_release(hrs_ctx* ctx, hrs_encoder* enc);
+/* ids_dev int32 [B, S] token ids (padded), lens_dev int32 [B] valid tokens per row, S a multiple of
+ * 32 in [32, 256]; out_dev fp32 [B, hidden] unit-norm sentence embeddings. */
+int hrs_encode(hrs_ctx* ctx, hrs_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S,
+               float* out_dev, void* stream);
+
 /* ---- keyword side -------------------------------------------------------------------------- */
 /* Forward CSR postings of this shard: the term ids of row i are
  * term_ids_dev[doc_offs_dev[i] .. doc_offs_dev[i+1]).  The handle keeps both pointers. */

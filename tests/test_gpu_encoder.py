@@ -1,0 +1,71 @@
+"""GPU encoder (bf16 MFMA) against the fp32 CPU oracle; tolerance from BASELINE.json: cosine >= 0.999."""
+import numpy as np
+import pytest
+import torch
+
+from hybrid_rag_system_amd import weights as W
+from oracle import encoder_oracle as EO
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 0.999  # north_star: "embeddings match within cosine >= 0.999"
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from hybrid_rag_system_amd.engine import Engine
+
+    eng = Engine(0)
+    cfg = W.EncoderConfig()
+    w = W.generate(cfg, seed=2026)
+    enc = eng.encoder(w, cfg)
+    yield eng, enc, w, cfg
+    enc.close()
+    eng.close()
+
+
+def _inputs(B, S, seed, full=False):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1000, 30000, (B, S)).astype(np.int32)
+    lens = np.full(B, S, np.int32) if full else rng.integers(3, S + 1, B).astype(np.int32)
+    lens[0] = S
+    if B > 1 and not full:
+        lens[1] = 1
+    ids[:, 0] = 101
+    for b in range(B):
+        ids[b, lens[b] - 1] = 102
+        ids[b, lens[b]:] = 0
+    return ids, lens
+
+
+@pytest.mark.parametrize("B,S", [(16, 256), (5, 64), (8, 32), (3, 160), (40, 128)])
+def test_encoder_matches_oracle(setup, B, S):
+    eng, enc, w, cfg = setup
+    ids, lens = _inputs(B, S, seed=B * 1000 + S)
+    want = EO.forward(w, ids, lens, cfg).numpy()
+    got = enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    cos = (got * want).sum(1)
+    assert cos.min() >= COS_TOL, cos
+    # random-token inputs share a large common component; the part that distinguishes inputs must match too
+    if B >= 5:
+        gc, wc = got - got.mean(0), want - want.mean(0)
+        ccos = (gc * wc).sum(1) / (np.linalg.norm(gc, axis=1) * np.linalg.norm(wc, axis=1))
+        assert ccos.min() > 0.98, ccos
+    assert np.abs(got - want).max() < 5e-3
+
+
+def test_padding_does_not_leak(setup):
+    """Tokens past `lens` must not influence the embedding."""
+    eng, enc, w, cfg = setup
+    ids, lens = _inputs(8, 128, seed=5)
+    a = enc.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
+    ids2 = ids.copy()
+    rng = np.random.default_rng(6)
+    for b in range(8):
+        ids2[b, lens[b]:] = rng.integers(1000, 30000, 128 - lens[b])
+    b2 = enc.encode_ids(torch.from_numpy(ids2).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
+    assert np.array_equal(a, b2)
