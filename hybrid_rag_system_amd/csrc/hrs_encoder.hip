@@ -229,6 +229,181 @@ __global__ __launch_bounds__(512) void k_gemm(GemmArgs a) {
     }
 }
 
+
+// ---- weights-stationary GEMM for K = 384 ----------------------------------------------------------
+// For the three GEMMs whose depth is the hidden size (QKV, attention output, FFN up) the weights fit
+// the register file: a workgroup of 12 waves holds 384 output features (each wave 32 features x 384
+// depth = 96 VGPRs) and streams 64-token activation tiles through a 3-deep LDS ring (LDS-DMA, two
+// tiles in flight, one barrier per tile) -- the scan kernel's structure with an output epilogue.
+// No weight byte is ever re-read; activations are read once per 384-feature group.
+struct GemmWsArgs {
+    const __bf16* A;     // [M, 384]
+    const __bf16* W;     // [N, 384]
+    const float* bias;   // [N]
+    __bf16* C;           // [M, N] (EPI_GELU)
+    __bf16* q;
+    __bf16* k;
+    __bf16* vf;
+    int M, N, S;
+    float qscale;
+};
+
+template <int EPI, bool VW>
+__device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
+    constexpr int KS = 24, TR = 64, RB = 768, TILE_BYTES = TR * RB, IPW = 4, PPR = 48, NST = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, i = lane & 31;
+    const int ngroups = a.N / 384;
+    const int nslices = (int)gridDim.x / ngroups;
+    const int fg = (int)blockIdx.x % ngroups;
+    const int slice = (int)blockIdx.x / ngroups;
+    if (slice >= nslices) return;
+    const int wfeat = fg * 384 + wv * 32;  // this wave's 32 output features
+    constexpr bool vwave = VW;
+
+    bf16x8 wf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8*)(a.W + (size_t)(wfeat + i) * 384 + s * 16 + h * 8);
+    // this workgroup's 384 biases live in LDS behind the tile ring (read back in the epilogue)
+    float* bias_lds = (float*)(smem + 3 * TILE_BYTES);
+    if (threadIdx.x < 384) bias_lds[threadIdx.x] = a.bias[fg * 384 + threadIdx.x];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s]));
+
+    const int tiles = a.M / TR;
+    const int t_begin = (int)((int64_t)tiles * slice / nslices);
+    const int t_end = (int)((int64_t)tiles * (slice + 1) / nslices);
+    const int count = t_end - t_begin;
+    if (count <= 0) return;
+
+    int srcoff[IPW];
+#pragma unroll
+    for (int ii = 0; ii < IPW; ++ii) {
+        const int g = (wv * IPW + ii) * 64 + lane;
+        const int r = g / PPR, p = g % PPR;
+        srcoff[ii] = r * RB + ((p ^ (r & 15)) << 4);
+    }
+    const uint32_t lds0 = lds_addr_of(smem);
+    auto issue = [&](int n, int buf) {
+        if (n >= count) n = count - 1;
+        const char* base = uniform_ptr((const char*)a.A + (size_t)(t_begin + n) * TILE_BYTES);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + wv * (IPW * 1024));
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+    };
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    const int rowoff = (int)lds0 + i * RB;
+    const int vx = h ^ (i & 15);
+
+    issue(0, 0);
+    issue(1, 1);
+    int buf = 0;
+    for (int n = 0; n < count; ++n) {
+        // outstanding, oldest first: DMA(n), DMA(n+1), the NST stores of tile n-1 (none before the first tile:
+        // the wait is then merely stricter than needed)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            int nb = buf + 2;
+            if (nb >= 3) nb -= 3;
+            issue(n + 2, nb);
+        }
+        lds_cptr tb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(rowoff + buf * TILE_BYTES + (((2 * c) ^ vx) << 4));
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            constexpr int PF = 4;
+            bf16x8 av[KS];
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+                av[s] = *(const __attribute__((address_space(3))) bf16x8*)(tb[s & 7] + sb * 32 * RB + (s >> 3) * 256);
+            if (vwave) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (s + PF < KS)
+                        av[s + PF] = *(const __attribute__((address_space(3))) bf16x8*)(tb[(s + PF) & 7] + sb * 32 * RB + ((s + PF) >> 3) * 256);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], wf[s], acc, 0, 0, 0);  // D[token][feature]
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (s + PF < KS)
+                        av[s + PF] = *(const __attribute__((address_space(3))) bf16x8*)(tb[(s + PF) & 7] + sb * 32 * RB + ((s + PF) >> 3) * 256);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], av[s], acc, 0, 0, 0);  // D[feature][token]
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+            for (int s = 0; s < KS - PF; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
+
+            const int tok0 = (t_begin + n) * TR + sb * 32;
+            if (vwave) {
+                // lane <-> feature d = i (+ head), registers <-> tokens tok0 + (r&3) + 8(r>>2) + 4h
+                const int head = (wfeat - 768) >> 5;
+                const int b = tok0 / a.S, sp0 = tok0 % a.S;  // 32-token tiles never straddle sequences (S % 32 == 0)
+                const int kt = sp0 >> 5;
+                __bf16* vb = a.vf + (((size_t)b * ENC_HEADS + head) * (a.S >> 5) + kt) * 1024 + (h * 32 + i) * 8;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[4 * g + e] + bias_lds[wv * 32 + i]);
+                    *(bf16x4*)(vb + (g >> 1) * 512 + (g & 1) * 4) = o;
+                }
+            } else {
+                const int token = tok0 + i;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = wfeat + 8 * g + 4 * h;
+                    const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
+                    float v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
+                    float v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
+                    bf16x4 o;
+                    if (EPI == EPI_GELU) {
+                        o[0] = (__bf16)gelu_erf(v0);
+                        o[1] = (__bf16)gelu_erf(v1);
+                        o[2] = (__bf16)gelu_erf(v2);
+                        o[3] = (__bf16)gelu_erf(v3);
+                        *(bf16x4*)(a.C + (size_t)token * a.N + f) = o;
+                    } else {
+                        const float sc = fg == 0 ? a.qscale : 1.0f;
+                        o[0] = (__bf16)(v0 * sc);
+                        o[1] = (__bf16)(v1 * sc);
+                        o[2] = (__bf16)(v2 * sc);
+                        o[3] = (__bf16)(v3 * sc);
+                        const int hf = f - fg * 384;
+                        const int b = token / a.S, sp = token % a.S;
+                        __bf16* dst = (fg == 0 ? a.q : a.k) + (((size_t)b * ENC_HEADS + (hf >> 5)) * a.S + sp) * ENC_DH + (hf & 31);
+                        *(bf16x4*)dst = o;
+                    }
+                }
+            }
+        }
+        buf = buf + 1 == 3 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(768) void k_gemm_ws(GemmWsArgs a) {
+    // the V third of the QKV projection is produced with the operands swapped (feature on the lane)
+    if (EPI == EPI_QKV && (int)blockIdx.x % (a.N / 384) == 2)
+        gemm_ws_body<EPI, true>(a);
+    else
+        gemm_ws_body<EPI, false>(a);
+}
+
 // ---- attention -----------------------------------------------------------------------------------
 // One workgroup (4 waves) per (sequence, head); a wave owns 32-query tiles. With S <= 256 the whole
 // score row lives in registers: S^T = K Q^T puts the query on the lane, so the row maximum and sum
@@ -251,72 +426,74 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     const int bh = blockIdx.x;
     const int b = bh / ENC_HEADS, head = bh % ENC_HEADS;
     const int S = NKT * 32;
-    const int len = a.lens[b];
+    int len = a.lens[b];
+    if (len > S) len = S;
+    const int nkt = len > 0 ? (len + 31) >> 5 : 1;  // key tiles that hold at least one valid key
     const __bf16* qb = a.q + (size_t)bh * S * ENC_DH;
     const __bf16* kb = a.k + (size_t)bh * S * ENC_DH;
     const __bf16* vb = a.vf + (size_t)bh * S * ENC_DH;
-
-    // K fragments (first operand, rows = keys): lane (i, h), k-step ks -> K[32 kt + i][16 ks + 8 h ..]
-    bf16x8 kf[NKT][2];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kf[kt][ks] = *(const bf16x8*)(kb + (kt * 32 + i) * ENC_DH + ks * 16 + h * 8);
 
     for (int qt = wv; qt < NKT; qt += 4) {
         bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + (qt * 32 + i) * ENC_DH + ks * 16 + h * 8);
-        f32x16 sc[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], sc[kt], 0, 0, 0);
-        }
-        // sc[kt][r] = score(query qt*32 + i, key kt*32 + (r&3) + 8(r>>2) + 4h), in log2 units
+        // pass 1: row maximum (scores are recomputed in pass 2: two MFMAs per tile are cheaper than keeping
+        // the whole row in registers, which would leave one wave per SIMD and nothing to hide latency with)
         float m = -1e30f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 sc;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kb + (kt * 32 + i) * ENC_DH + ks * 16 + h * 8);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = key < len ? sc[kt][r] : -1e30f;
-                sc[kt][r] = v;
-                m = fmaxf(m, v);
+                m = fmaxf(m, key < len ? sc[r] : -1e30f);
             }
+        }
         m = fmaxf(m, __shfl_xor(m, 32));
+        // pass 2: p = 2^(s - m), l = sum p, O += P V
         float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(sc[kt][r] - m);
-                sc[kt][r] = p;
-                l += p;
-            }
-        l += __shfl_xor(l, 32);
-        const float inv = 1.0f / l;
-        // O = P V: first operand = P (registers 8 s2 .. 8 s2 + 7 of tile kt), second = V fragments
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 sc;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kb + (kt * 32 + i) * ENC_DH + ks * 16 + h * 8);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float p = key < len ? __builtin_amdgcn_exp2f(sc[r] - m) : 0.f;
+                sc[r] = p;
+                l += p;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)(sc[kt][8 * s2 + e] * inv);
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s2 + e];
                 const bf16x8 vfrag = *(const bf16x8*)(vb + ((kt * 2 + s2) * 64 + lane) * 8);
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vfrag, o, 0, 0, 0);
             }
-        // o[r] = O[query qt*32 + (r&3) + 8(r>>2) + 4h][column i]
+        }
+        l += __shfl_xor(l, 32);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;  // per query, held by the lanes whose i is that query
+        // o[r] = O[query qt*32 + (r&3) + 8(r>>2) + 4h][column i]: fetch each row's 1/l from its lane
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qrow = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            a.ctx[((size_t)b * S + qrow) * ENC_H + head * ENC_DH + i] = (__bf16)o[r];
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float w = __shfl(inv, qi);
+            a.ctx[((size_t)b * S + qt * 32 + qi) * ENC_H + head * ENC_DH + i] = (__bf16)(o[r] * w);
         }
     }
 }
@@ -556,6 +733,23 @@ static int launch_gemm(hrs_ctx* ctx, const GemmArgs& g, hipStream_t st) {
     return HRS_OK;
 }
 
+template <int EPI>
+static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    const int lds = 3 * 64 * 768 + 384 * 4;
+    if (!attr_set) {
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_ws<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ngroups = g.N / 384;
+    int grid = ctx->num_cu / ngroups * ngroups;
+    const int tiles = g.M / 64;
+    if (tiles * ngroups < grid) grid = tiles * ngroups;
+    hipLaunchKernelGGL((k_gemm_ws<EPI>), dim3(grid), dim3(768), lds, st, g);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
 static int launch_attention(const AttnArgs& a, int B, hipStream_t st) {
     const int nkt = a.S / 32;
     const dim3 grid(B * ENC_HEADS), block(256);
@@ -608,19 +802,19 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
     for (int l = 0; l < e->cfg.layers; ++l) {
         const hrs_encoder::Layer& L = e->layer[l];
         GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.M = M;
-        g.S = S;
-        g.A = x;
-        g.W = L.wqkv;
-        g.bias = L.bqkv;
-        g.N = 3 * H;
-        g.K = H;
-        g.q = q;
-        g.k = k;
-        g.vf = vf;
-        g.qscale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e): softmax in base 2
-        if ((rc = launch_gemm<EPI_QKV>(ctx, g, st))) return rc;
+        GemmWsArgs gw;
+        memset(&gw, 0, sizeof(gw));
+        gw.M = M;
+        gw.S = S;
+        gw.A = x;
+        gw.W = L.wqkv;
+        gw.bias = L.bqkv;
+        gw.N = 3 * H;
+        gw.q = q;
+        gw.k = k;
+        gw.vf = vf;
+        gw.qscale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e): softmax in base 2
+        if ((rc = launch_gemm_ws<EPI_QKV>(ctx, gw, st))) return rc;
         AttnArgs at;
         at.q = q;
         at.k = k;
@@ -641,14 +835,17 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         g.K = H;
         if ((rc = launch_gemm<EPI_RESID>(ctx, g, st))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, L.ln1g, L.ln1b, M, e->cfg.eps, y);
-        g.A = y;
-        g.W = L.wi;
-        g.bias = L.bi;
-        g.resid = nullptr;
-        g.C = hbuf;
-        g.N = I;
-        g.K = H;
-        if ((rc = launch_gemm<EPI_GELU>(ctx, g, st))) return rc;
+        gw.A = y;
+        gw.W = L.wi;
+        gw.bias = L.bi;
+        gw.C = hbuf;
+        gw.N = I;
+        if ((rc = launch_gemm_ws<EPI_GELU>(ctx, gw, st))) return rc;
+        memset(&g, 0, sizeof(g));
+        g.M = M;
+        g.S = S;
+        g.C = pre;
+        g.N = H;
         g.A = hbuf;
         g.W = L.wd;
         g.bias = L.bd;
