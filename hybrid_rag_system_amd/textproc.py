@@ -1,0 +1,107 @@
+"""Host-side string work of the helper: cleaning, chunking, ids, metadata heuristics, keywords.
+
+These stay on the CPU (micro-seconds per document) and reproduce the reference's behaviour exactly;
+each function cites the reference lines it mirrors (scripts/chromadb_helper.py).
+"""
+import hashlib
+import re
+
+_WS = re.compile(r"\s+")
+# break points, best first (chromadb_helper.py:142-148); the text is whitespace-collapsed before
+# chunking, so the paragraph pattern can never fire -- it is kept because the reference tries it
+_BREAK_RES = [re.compile(p) for p in (r"\n\n", r"\.\s+", r"[;:]\s+", r",\s+", r"\s+")]
+_WORD = re.compile(r"\b[a-z]+\b")
+_TITLE = re.compile(r"^#\s+(.+)$", re.MULTILINE)
+
+STOPWORDS = frozenset((
+    "the a an is are was were be been being have has had do does did will would could should may "
+    "might can to of in for on with at by from as into through during before after above below "
+    "between under again further then once here there when where why how all each few more most "
+    "other some such no nor not only own same so than too very just and but if or because until "
+    "while this that these those what which who whom my your his her its our their i me you he she "
+    "it we they"
+).split())
+
+SYSTEM_RULES = {
+    "unraid": (r"\bunraid\b", r"\b/mnt/user\b", r"\barray\b"),
+    "proxmox": (r"\bproxmox\b", r"\bpve\b", r"\blxc\b", r"\bqemu\b"),
+    "windows": (r"\bpowershell\b", r"\bactive directory\b", r"\bsccm\b"),
+    "docker": (r"\bdocker\b", r"\bcontainer\b", r"\bcompose\b"),
+    "network": (r"\bunifi\b", r"\bvlan\b", r"\bfirewall\b"),
+}
+_CATEGORY_RULES = (
+    (("troubleshoot",), "troubleshooting"),
+    (("howto", "guide"), "howto"),
+    (("reference", "api"), "reference"),
+    (("config",), "configuration"),
+)
+
+
+def clean_text(text):
+    """chromadb_helper.py:93-99."""
+    return _WS.sub(" ", text).replace("\x00", "").strip()
+
+
+def chunk_text(text, chunk_size, overlap):
+    """chromadb_helper.py:102-173: windows of chunk_size chars, cut at the last break point found in
+    the final fifth of the window, next window starting `overlap` chars before the cut."""
+    text = clean_text(text)
+    total = len(text)
+    if total <= chunk_size:
+        return [{"content": text, "chunk_index": 0, "char_start": 0, "char_end": total, "total_chunks": 1}]
+    tail = int(chunk_size * 0.2)
+    pieces = []
+    pos = 0
+    while pos < total:
+        cut = pos + chunk_size
+        if cut < total:
+            base = cut - tail
+            view = text[base:cut]
+            for rx in _BREAK_RES:
+                ends = [m.end() for m in rx.finditer(view)]
+                if ends:
+                    cut = base + ends[-1]
+                    break
+        body = text[pos:cut].strip()
+        if body:
+            pieces.append({"content": body, "chunk_index": len(pieces), "char_start": pos, "char_end": cut})
+        pos = cut - overlap
+    for p in pieces:
+        p["total_chunks"] = len(pieces)
+    return pieces
+
+
+def generate_doc_id(content, source=""):
+    """chromadb_helper.py:223-226."""
+    return hashlib.sha256((source + ":" + content[:500]).encode()).hexdigest()[:16]
+
+
+def extract_metadata_from_content(content, filepath=None):
+    """chromadb_helper.py:176-220."""
+    meta = {}
+    lowered = content.lower()
+    systems = [name for name, pats in SYSTEM_RULES.items() if any(re.search(p, lowered) for p in pats)]
+    if systems:
+        meta["system"] = systems[0]
+        meta["systems"] = ",".join(systems)
+    if filepath:
+        low = filepath.lower()
+        meta["category"] = next((cat for keys, cat in _CATEGORY_RULES if any(k in low for k in keys)), "general")
+        meta["filepath"] = filepath
+    m = _TITLE.search(content)
+    if m:
+        meta["title"] = m.group(1).strip()[:200]
+    return meta
+
+
+def extract_keywords(text):
+    """chromadb_helper.py:328-349 (a set turned into a list: order is not part of the contract)."""
+    return list({w for w in _WORD.findall(text.lower()) if len(w) > 2 and w not in STOPWORDS})
+
+
+def calculate_keyword_score(document, keywords):
+    """chromadb_helper.py:352-359: fraction of keywords that occur as substrings of the document."""
+    if not keywords:
+        return 0.0
+    hay = document.lower()
+    return sum(1 for k in keywords if k in hay) / len(keywords)

@@ -1,0 +1,116 @@
+"""BASELINE config 1 end to end on the GPU: index context/infrastructure/*.md (63 chunks), then
+`query --hybrid --n-results 5`, through the helper / bridge surface."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_oracle as EO
+from oracle import search_oracle as so
+from oracle import text_oracle as T
+
+pytestmark = pytest.mark.gpu
+
+CORPUS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "context", "infrastructure")
+QUERIES = [
+    "How do I restart the nginx container on Unraid?",
+    "powershell Get-ADUser filter examples",
+    "bash loop over files in a directory",
+    "proxmox lxc container backup schedule",
+    "the and of to in",
+]
+
+
+@pytest.fixture(scope="module")
+def helper(tmp_path_factory):
+    data = tmp_path_factory.mktemp("hrs_data")
+    os.environ["HRS_DATA_DIR"] = str(data)
+    import importlib
+
+    from hybrid_rag_system_amd import helper as h
+
+    importlib.reload(h)
+    yield h
+
+
+def test_index_then_hybrid_query(helper):
+    res = helper.index_directory(CORPUS_DIR, ["*.md"], "cfg1")
+    assert res["status"] == "success" and res["indexed"] == 4 and res["failed"] == 0
+    assert sorted(f["chunks"] for f in res["files"]) == [6, 14, 15, 28]
+    col = helper.get_collection("cfg1")
+    assert col.count() == 63
+    # indexing again adds nothing: existing ids are kept
+    helper.index_directory(CORPUS_DIR, ["*.md"], "cfg1")
+    assert col.count() == 63
+    emb = col._emb
+    assert emb.shape == (63, 384) and np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-5
+
+    # encoder vs the fp32 oracle on the same token ids (tolerance: cosine >= 0.999)
+    ef = helper.get_embedding_function()
+    ids, lens = ef.tokenizer.encode_batch(col.documents)
+    from hybrid_rag_system_amd import weights as W
+
+    want = EO.forward(W.generate(ef.cfg, 2026), ids, lens, ef.cfg).numpy()
+    cos = (want * emb).sum(1)
+    assert cos.min() >= 0.999, cos.min()
+
+    recalls = []
+    for q in QUERIES:
+        got = helper.hybrid_query(q, 5, "cfg1")
+        qe = helper.embed([q]).cpu().numpy()
+        # search parity on identical fp32 embeddings: ids and distances bit-exact
+        wd, wr = so.topk(qe, emb, 10, "l2")
+        raw = helper.query(q, 10, "cfg1")
+        assert raw["ids"][0] == [col.ids[r] for r in wr[0]]
+        assert raw["distances"][0] == [float(x) for x in wd[0]]
+        # fusion parity: the reference's arithmetic on those candidates
+        want_rows = T.fuse([col.documents[r] for r in wr[0]], [col.metadatas[r] for r in wr[0]], [col.ids[r] for r in wr[0]], [float(x) for x in wd[0]], q, 5)
+        assert got == want_rows
+        assert len(got) == 5 and all(set(g) == {"document", "metadata", "id", "semantic_score", "keyword_score", "combined_score", "distance"} for g in got)
+        # recall against the all-fp32 pipeline (oracle encoder + oracle search + reference fusion)
+        qi, ql = ef.tokenizer.encode_batch([q])
+        qo = EO.forward(W.generate(ef.cfg, 2026), qi, ql, ef.cfg).numpy()
+        od, orows = so.topk(qo, want, 10, "l2")
+        ref_rows = T.fuse([col.documents[r] for r in orows[0]], [col.metadatas[r] for r in orows[0]], [col.ids[r] for r in orows[0]], [float(x) for x in od[0]], q, 5)
+        recalls.append(len({g["id"] for g in got} & {r["id"] for r in ref_rows}) / 5)
+    print("hybrid top-5 recall vs fp32 pipeline per query:", recalls)
+    assert np.mean(recalls) >= 0.8  # generated weights give near-degenerate distances; see DESIGN.md
+
+
+def test_persistence_where_filter_and_bridge(helper):
+    from hybrid_rag_system_amd import bridge
+    from hybrid_rag_system_amd.store import Client
+
+    fresh = Client(os.environ["HRS_DATA_DIR"])
+    col = fresh.get_or_create_collection("cfg1")
+    assert col.count() == 63 and [c.name for c in fresh.list_collections()] == ["cfg1"]
+    systems = sorted({m.get("system") for m in col.metadatas if m.get("system")})
+    assert systems
+    sysname = systems[0]
+    n_sys = sum(1 for m in col.metadatas if m.get("system") == sysname)
+    res = helper.query("container restart", 5, "cfg1", {"system": sysname})
+    assert len(res["metadatas"][0]) == min(5, n_sys) and all(m["system"] == sysname for m in res["metadatas"][0])
+    none = helper.query("container restart", 5, "cfg1", {"system": "no-such-system"})
+    assert none["ids"] == [[]]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bridge.main(["query", QUERIES[0], "--hybrid", "--n-results", "3", "--collection", "cfg1"])
+    out = json.loads(buf.getvalue())
+    assert out["success"] and out["count"] == 3 and [r["index"] for r in out["results"]] == [1, 2, 3]
+    assert all(set(r) == {"index", "document", "full_length", "metadata", "combined_score", "semantic_score", "keyword_score"} for r in out["results"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bridge.main(["query", QUERIES[0], "--n-results", "2", "--collection", "cfg1", "--system", sysname])
+    out = json.loads(buf.getvalue())
+    assert out["success"] and out["count"] == 2 and "similarity" in out["results"][0] and "distance" in out["results"][0]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bridge.main(["stats", "--collection", "cfg1"])
+    st = json.loads(buf.getvalue())
+    assert st["success"] and st["stats"]["count"] == 63
+    batch = helper.hybrid_query_batch(QUERIES, 5, "cfg1")
+    assert [r["id"] for r in batch[0]] == [r["id"] for r in helper.hybrid_query(QUERIES[0], 5, "cfg1")]
