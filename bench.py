@@ -91,6 +91,49 @@ def cpu_baseline(corpus_matrix, terms, queries, q_terms, q_offs, n_keep, n_total
     }
 
 
+def bench_embed(eng, batches=4, B=1024, S=256):
+    """BASELINE config 3 shape: MiniLM-L6 embedding of full-length (256-token) synthetic chunks, batch 1024."""
+    from hybrid_rag_system_amd import weights as W
+
+    cfg = W.EncoderConfig()
+    enc = eng.encoder(W.generate(cfg, 2026), cfg)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ids = torch.randint(1000, 30000, (B, S), generator=g, dtype=torch.int32)
+    ids[:, 0], ids[:, -1] = 101, 102
+    ids = ids.to(eng.device)
+    lens = torch.full((B,), S, dtype=torch.int32, device=eng.device)
+    for _ in range(2):
+        enc.encode_ids(ids, lens)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        enc.encode_ids(ids, lens)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / batches
+    enc.close()
+    flops = 6.040e9 * B  # 23 592 960 flop per token x 256 tokens
+    return {"chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "tflops": flops / dt / 1e12, "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
+            "config": f"MiniLM-L6 geometry, generated weights, batch {B} x {S} tokens, bf16 MFMA"}
+
+
+def bench_scan(eng, corpus, queries, k=10):
+    """The small-batch streaming scan (fp64-exact, fp32 corpus read once per pass of <= 4 queries)."""
+    out = {}
+    for b in (1, 4):
+        q = queries[:b].contiguous()
+        eng.score_topk(corpus, q, k, mode="exact")
+        torch.cuda.synchronize()
+        eng.profile(True)
+        for _ in range(5):
+            eng.score_topk(corpus, q, k, mode="exact")
+        torch.cuda.synchronize()
+        ms, n = eng.profile_read()
+        eng.profile(False)
+        gbps = corpus.n * corpus.dim * 4 / (ms / n * 1e-3) / 1e9
+        out[f"B{b}"] = {"kernel_ms": ms / n, "algorithmic_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS, "queries_per_s": b / (ms / n * 1e-3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +147,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
+    ap.add_argument("--no-extras", action="store_true", help="skip the embed / small-batch scan side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,6 +258,8 @@ def main():
             "fallback_queries_per_batch": stats["fallback_queries"],
             "max_candidates": stats["max_candidates"],
         }
+        if world == 1 and not args.no_extras:
+            line["extras"] = {"embed": bench_embed(eng), "exact_scan": bench_scan(eng, corpus, queries)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(matrix, terms, queries, q_terms, q_offs, n_keep, n_total, args.cpu_sample_rows, args.cpu_sample_queries)
         else:

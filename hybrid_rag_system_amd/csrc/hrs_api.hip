@@ -128,7 +128,7 @@ extern "C" int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, 
                                    void* stream, hrs_corpus** out) {
     HRS_REQUIRE(ctx && out, "hrs_corpus_register: null ctx/out");
     HRS_REQUIRE(N >= 0 && (N == 0 || C_dev), "hrs_corpus_register: N=%lld with null matrix", (long long)N);
-    HRS_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "hrs_corpus_register: D=%d must be a multiple of 4 in (0, 8192]", D);
+    HRS_REQUIRE(D > 0 && D % 4 == 0 && D <= 2048, "hrs_corpus_register: D=%d must be a multiple of 4 in (0, 2048]", D);
     HRS_REQUIRE(row_offset >= 0 && N + row_offset < (1ll << 32), "hrs_corpus_register: rows beyond 2^32");
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     hrs_corpus* c = new hrs_corpus();

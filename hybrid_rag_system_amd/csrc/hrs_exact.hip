@@ -4,15 +4,20 @@
 // correctly rounded operation per step, then rounded once to fp32 -- the same operations the CPU
 // oracle performs -- so the (distance, row) order is exact by construction.  The kernel is bound
 // by the HBM stream of the fp32 corpus: one workgroup per CU walks a contiguous slice of rows;
-// 256-row x 64-float segments are brought into LDS by LDS-DMA (global_load_lds, 16 B per lane),
-// double buffered, and each thread owns one row of the tile.  The LDS image is lane-linear as the
-// DMA requires; bank conflicts of the per-row reads are avoided by permuting the 16-byte pieces
-// of a row on the SOURCE side (piece p of row r is stored at p ^ (r & 15)).
+// 128-row x 64-float segments (32 KB) arrive in a 4-deep LDS ring by LDS-DMA (three segments in
+// flight per CU, counted vmcnt, one barrier per segment).  A thread owns one row of the tile and
+// half of the pass's queries.  The LDS image is lane-linear as the DMA requires; bank conflicts of
+// the per-row reads are avoided by permuting the 16-byte pieces of a row on the SOURCE side
+// (piece p of row r is stored at p ^ (r & 15)).  Nothing in the loop touches global memory except
+// the DMA: the pass's queries are copied to LDS once, candidates live in LDS.
 #include "hrs_internal.h"
 
-#define ER 256   // rows per tile (one per thread)
+#define ER 128   // rows per tile
 #define EDC 64   // floats per row segment
-#define ETILE_BYTES (ER * EDC * 4)
+#define ENBUF 4  // ring depth
+#define ESEG_BYTES (ER * EDC * 4)
+#define EIPW 8   // LDS-DMA instructions per wave per segment (32 KB / 1 KB / 4 waves)
+#define EQ_FLOATS 2048  // fp32 query staging: BQ * D <= 2048
 
 struct ExactArgs {
     const float* C;
@@ -31,10 +36,12 @@ struct ExactArgs {
 
 template <int SPACE, int BQ>
 __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
+    constexpr int NQT = BQ >= 2 ? BQ / 2 : 1;  // queries per thread (two query slots per row)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: [2][ETILE_BYTES] tiles | [2][BQ][EDC] double q-chunks | [BQ][CB] keys | misc
-    char* tilebuf = smem;
-    double* qbuf = (double*)(smem + 2 * ETILE_BYTES);
+    // layout: ring [ENBUF][ESEG_BYTES] | qf32 [EQ_FLOATS] | qbuf [2][BQ][EDC] double | cand [BQ][CB] | misc
+    char* ring = smem;
+    float* qf32 = (float*)(smem + ENBUF * ESEG_BYTES);
+    double* qbuf = (double*)(qf32 + EQ_FLOATS);
     uint64_t* cand = (uint64_t*)(qbuf + 2 * BQ * EDC);
     uint64_t* tau = cand + BQ * HRS_EXACT_CB;
     double* qnorm = (double*)(tau + BQ);
@@ -44,6 +51,8 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_t = tid & (ER - 1);   // this thread's row inside a tile
+    const int qslot = tid >> 7;         // 0 or 1
     int nq = a.nq_dev ? *a.nq_dev : a.nq;
     if (nq > a.nq) nq = a.nq;
     if (nq <= 0) return;
@@ -54,6 +63,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
     const int64_t tile_end = a.tiles * (blockIdx.x + 1) / gridDim.x;
     const int64_t steps = (tile_end - tile_begin) * nchunks;
     const int npass = (nq + BQ - 1) / BQ;
+    const uint32_t ring0 = lds_addr_of(ring);
 
     for (int pass = 0; pass < npass; ++pass) {
         __syncthreads();
@@ -65,123 +75,145 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             tau[tid] = HRS_PAD_KEY;
         }
         __syncthreads();
+        for (int e = tid; e < BQ * D; e += 256) qf32[e] = a.Q[(size_t)qidx[e / D] * D + e % D];
+        __syncthreads();
         if (SPACE == HRS_SPACE_COSINE && tid < BQ) {
-            const float* q = a.Q + (size_t)qidx[tid] * D;
+            const float* q = qf32 + tid * D;
             double s = 0.0;
             for (int i = 0; i < D; ++i) s = fma((double)q[i], (double)q[i], s);
             qnorm[tid] = s;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the compiler's is in flight past here
 
-        auto stage_q = [&](int ch, int buf) {
-            // BQ x EDC doubles for the chunk; 256 threads
+        auto stage_q = [&](int ch, int buf) {  // LDS fp32 -> LDS fp64, this chunk of every query of the pass
             const int w = min(EDC, D - ch * EDC);
             for (int e = tid; e < BQ * EDC; e += 256) {
-                int b = e / EDC, i = e % EDC;
-                double v = 0.0;
-                if (i < w) v = (double)a.Q[(size_t)qidx[b] * D + ch * EDC + i];
-                qbuf[(buf * BQ + b) * EDC + i] = v;
+                const int b = e / EDC, i = e % EDC;
+                qbuf[(buf * BQ + b) * EDC + i] = i < w ? (double)qf32[b * D + ch * EDC + i] : 0.0;
             }
         };
-        auto issue_dma = [&](int64_t step, int buf) {
+        // per-lane source offsets of this wave's 8 pieces for a full-width segment of a full tile
+        int fastoff[EIPW];
+#pragma unroll
+        for (int i = 0; i < EIPW; ++i) {
+            const int r = wv * 32 + i * 4 + (lane >> 4);
+            fastoff[i] = (r * D + (((lane & 15) ^ (r & 15)) << 2)) * 4;
+        }
+        auto issue_dma = [&](int64_t step) {
+            if (step >= steps) step = steps - 1;  // keep the vmcnt bookkeeping uniform at the tail
             const int64_t tile = tile_begin + step / nchunks;
             const int ch = (int)(step % nchunks);
             const int wpieces = min(EDC, D - ch * EDC) >> 2;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(tilebuf) + buf * ETILE_BYTES + wv * 16384);
-            // scalar base = first row of the tile at this chunk; per-lane offsets stay below 2^31:
-            // 256 rows x D x 4 bytes <= 8 MB
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)(step % ENBUF) * ESEG_BYTES + wv * (EIPW * 1024));
             const char* base = uniform_ptr(a.C + tile * ER * (int64_t)D + ch * EDC);
             const int64_t rows_left = a.N - tile * ER;
+            if (wpieces == EDC / 4 && rows_left >= ER) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int r = wv * 64 + i * 4 + (lane >> 4);
-                int p = lane & 15;
-                int sp = p ^ (r & 15);
-                if (sp >= wpieces) sp = 0;
-                if (r >= rows_left) r = (int)rows_left - 1;
-                glds16_asm(base, (r * D + sp * 4) * 4, dst + i * 1024);
+                for (int i = 0; i < EIPW; ++i) glds16_asm(base, fastoff[i], dst + i * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < EIPW; ++i) {
+                    int r = wv * 32 + i * 4 + (lane >> 4);
+                    const int p = lane & 15;
+                    int sp = p ^ (r & 15);
+                    if (sp >= wpieces) sp = 0;
+                    if (r >= rows_left) r = (int)rows_left - 1;
+                    glds16_asm(base, (r * D + sp * 4) * 4, dst + i * 1024);
+                }
             }
         };
 
-        double acc[BQ];
+        double acc[NQT];
         double ncacc = 0.0;
         if (steps > 0) {
             stage_q(0, 0);
-            issue_dma(0, 0);
+            issue_dma(0);
+            issue_dma(1);
+            issue_dma(2);
         }
         for (int64_t step = 0; step < steps; ++step) {
-            const int cur = (int)(step & 1);
             const int ch = (int)(step % nchunks);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // segments step+1 and step+2 may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * EIPW) : "memory");
             __syncthreads();
-            if (step + 1 < steps) {
-                issue_dma(step + 1, cur ^ 1);
-                stage_q((int)((step + 1) % nchunks), cur ^ 1);
-            }
+            issue_dma(step + 3);
+            if (step + 1 < steps) stage_q((int)((step + 1) % nchunks), (int)((step + 1) & 1));
             if (ch == 0) {
 #pragma unroll
-                for (int b = 0; b < BQ; ++b) acc[b] = 0.0;
+                for (int b = 0; b < NQT; ++b) acc[b] = 0.0;
                 ncacc = 0.0;
             }
-            const int pieces = min(EDC, D - ch * EDC) >> 2;
-            const char* rowp = tilebuf + cur * ETILE_BYTES + tid * (EDC * 4);
-            const double* qb = qbuf + cur * BQ * EDC;
-            const int sw = tid & 15;
-            for (int s = 0; s < pieces; ++s) {
-                float4 cv = *(const float4*)(rowp + ((s ^ sw) << 4));
-                double c0 = (double)cv.x, c1 = (double)cv.y, c2 = (double)cv.z, c3 = (double)cv.w;
-                if (SPACE == HRS_SPACE_COSINE) {
-                    ncacc = fma(c0, c0, ncacc);
-                    ncacc = fma(c1, c1, ncacc);
-                    ncacc = fma(c2, c2, ncacc);
-                    ncacc = fma(c3, c3, ncacc);
-                }
-#pragma unroll
-                for (int b = 0; b < BQ; ++b) {
-                    const double* qp = qb + b * EDC + s * 4;
-                    double q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
-                    if (SPACE == HRS_SPACE_L2) {
-                        double d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
-                        acc[b] = fma(d0, d0, acc[b]);
-                        acc[b] = fma(d1, d1, acc[b]);
-                        acc[b] = fma(d2, d2, acc[b]);
-                        acc[b] = fma(d3, d3, acc[b]);
-                    } else {
-                        acc[b] = fma(q0, c0, acc[b]);
-                        acc[b] = fma(q1, c1, acc[b]);
-                        acc[b] = fma(q2, c2, acc[b]);
-                        acc[b] = fma(q3, c3, acc[b]);
+            if (BQ >= 2 || qslot == 0) {
+                const int pieces = min(EDC, D - ch * EDC) >> 2;
+                const char* rowp = ring + (step % ENBUF) * ESEG_BYTES + row_t * (EDC * 4);
+                const double* qb = qbuf + (step & 1) * BQ * EDC;
+                const int sw = row_t & 15;
+                auto piece = [&](int s) {
+                    const float4 cv = *(const float4*)(rowp + ((s ^ sw) << 4));
+                    const double c0 = (double)cv.x, c1 = (double)cv.y, c2 = (double)cv.z, c3 = (double)cv.w;
+                    if (SPACE == HRS_SPACE_COSINE) {
+                        ncacc = fma(c0, c0, ncacc);
+                        ncacc = fma(c1, c1, ncacc);
+                        ncacc = fma(c2, c2, ncacc);
+                        ncacc = fma(c3, c3, ncacc);
                     }
+#pragma unroll
+                    for (int b = 0; b < NQT; ++b) {
+                        const double* qp = qb + (BQ >= 2 ? qslot + 2 * b : 0) * EDC + s * 4;
+                        const double q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+                        if (SPACE == HRS_SPACE_L2) {
+                            const double d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
+                            acc[b] = fma(d0, d0, acc[b]);
+                            acc[b] = fma(d1, d1, acc[b]);
+                            acc[b] = fma(d2, d2, acc[b]);
+                            acc[b] = fma(d3, d3, acc[b]);
+                        } else {
+                            acc[b] = fma(q0, c0, acc[b]);
+                            acc[b] = fma(q1, c1, acc[b]);
+                            acc[b] = fma(q2, c2, acc[b]);
+                            acc[b] = fma(q3, c3, acc[b]);
+                        }
+                    }
+                };
+                if (pieces == EDC / 4) {
+                    // full segment: unrolled, so the LDS reads of all 16 pieces are in flight together
+#pragma unroll
+                    for (int s = 0; s < EDC / 4; ++s) piece(s);
+                } else {
+                    for (int s = 0; s < pieces; ++s) piece(s);
                 }
             }
             if (ch == nchunks - 1) {
                 const int64_t tile = tile_begin + step / nchunks;
-                const int64_t row = tile * ER + tid;
-                bool live = row < a.N;
+                const int64_t row = tile * ER + row_t;
+                bool live = row < a.N && (BQ >= 2 || qslot == 0);
                 if (live && a.mask) live = a.mask[row] != 0;
                 if (live) {
                     const uint32_t grow = (uint32_t)(row + a.row_offset);
 #pragma unroll
-                    for (int b = 0; b < BQ; ++b) {
+                    for (int b = 0; b < NQT; ++b) {
+                        const int qb_i = BQ >= 2 ? qslot + 2 * b : 0;
                         double d;
                         if (SPACE == HRS_SPACE_L2) {
                             d = acc[b];
                         } else if (SPACE == HRS_SPACE_IP) {
                             d = 1.0 - acc[b];
                         } else {
-                            double nqv = qnorm[b];
+                            const double nqv = qnorm[qb_i];
                             d = (nqv == 0.0 || ncacc == 0.0) ? 1.0 : 1.0 - acc[b] / (sqrt(nqv) * sqrt(ncacc));
                         }
-                        uint64_t key = pack_key((float)d, grow);
-                        if (key < tau[b]) {
-                            int pos = atomicAdd(&cnt[b], 1);
-                            cand[b * HRS_EXACT_CB + pos] = key;  // pos < CB: cnt <= CB-ER before a tile
+                        const uint64_t key = pack_key((float)d, grow);
+                        if (key < tau[qb_i]) {
+                            const int pos = atomicAdd(&cnt[qb_i], 1);
+                            cand[qb_i * HRS_EXACT_CB + pos] = key;  // pos < CB: cnt <= CB - ER before a tile
                         }
                     }
                 }
+                if (a.mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 // compact any list that could overflow during the next tile
                 for (int b = 0; b < BQ; ++b) {
-                    int c = cnt[b];
+                    const int c = cnt[b];
                     if (c > HRS_EXACT_CB - ER) {
                         uint64_t* cb = cand + b * HRS_EXACT_CB;
                         for (int i = c + tid; i < HRS_EXACT_CB; i += 256) cb[i] = HRS_PAD_KEY;
@@ -195,12 +227,13 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // final: sort each list, emit k keys
         for (int b = 0; b < BQ; ++b) {
-            int j = pass * BQ + b;
+            const int j = pass * BQ + b;
             if (j >= nq) break;
-            int c = cnt[b];
+            const int c = cnt[b];
             uint64_t* cb = cand + b * HRS_EXACT_CB;
             for (int i = c + tid; i < HRS_EXACT_CB; i += 256) cb[i] = HRS_PAD_KEY;
             bitonic_sort_u64(cb, HRS_EXACT_CB, tid, 256);
@@ -249,8 +282,8 @@ __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
 
 template <int SPACE, int BQ>
 static int launch_exact_t(const ExactArgs& a, int grid, hipStream_t st) {
-    size_t lds = 2 * ETILE_BYTES + 2 * BQ * EDC * sizeof(double) + BQ * HRS_EXACT_CB * sizeof(uint64_t) +
-                 BQ * (sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
+    size_t lds = ENBUF * ESEG_BYTES + EQ_FLOATS * sizeof(float) + 2 * BQ * EDC * sizeof(double) +
+                 BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
     static bool attr_set = false;
     if (!attr_set) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ>,
@@ -298,7 +331,12 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     a.mask = mask;
     a.partial = p0;
     a.tiles = tiles;
-    const int bq = nq_dev ? 4 : B;
+    int bq = nq_dev ? 4 : B;
+    if (bq * c->D > EQ_FLOATS) bq = EQ_FLOATS / c->D;  // the pass's queries are staged in LDS as fp32
+    if (bq < 1) {
+        hrs_set_error("exact scan: D=%d exceeds %d", c->D, EQ_FLOATS);
+        return HRS_ERR_UNSUPPORTED;
+    }
     if (c->N > 0) {
         if (!nq_dev) hrs_prof_begin(ctx, st);
         if (space == HRS_SPACE_L2)
