@@ -421,69 +421,95 @@ struct AttnArgs {
 
 template <int NKT>
 __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // K (swizzled: 16-byte piece p of key row r at p ^ ((r >> 2) & 3), so that the 16 rows a
+    // ds_read_b128 lane group touches fall on 16 different bank groups) and V (already in fragment
+    // order) of this (sequence, head), shared by the four waves and by both passes
+    __shared__ __attribute__((aligned(16))) char lds[2 * NKT * 32 * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int h = lane >> 5, i = lane & 31;
     const int bh = blockIdx.x;
     const int b = bh / ENC_HEADS, head = bh % ENC_HEADS;
-    const int S = NKT * 32;
+    constexpr int S = NKT * 32;
     int len = a.lens[b];
     if (len > S) len = S;
     const int nkt = len > 0 ? (len + 31) >> 5 : 1;  // key tiles that hold at least one valid key
-    const __bf16* qb = a.q + (size_t)bh * S * ENC_DH;
-    const __bf16* kb = a.k + (size_t)bh * S * ENC_DH;
-    const __bf16* vb = a.vf + (size_t)bh * S * ENC_DH;
+    const char* qb = (const char*)(a.q + (size_t)bh * S * ENC_DH);
+    const char* kb = (const char*)(a.k + (size_t)bh * S * ENC_DH);
+    const char* vb = (const char*)(a.vf + (size_t)bh * S * ENC_DH);
+    char* klds = lds;
+    char* vlds = lds + NKT * 32 * 64;
+    for (int pc = tid; pc < nkt * 128; pc += 256) {  // 16-byte pieces: 4 per key row
+        const int r = pc >> 2, p = pc & 3;
+        *(uint4*)(klds + r * 64 + ((p ^ ((r >> 2) & 3)) << 4)) = *(const uint4*)(kb + pc * 16);
+        *(uint4*)(vlds + pc * 16) = *(const uint4*)(vb + pc * 16);
+    }
+    __syncthreads();
+    const int koff0 = i * 64 + (((0 + h) ^ ((i >> 2) & 3)) << 4);  // k-step 0 wants piece h, k-step 1 piece 2 + h
+    const int koff1 = i * 64 + (((2 + h) ^ ((i >> 2) & 3)) << 4);
 
     for (int qt = wv; qt < NKT; qt += 4) {
         bf16x8 qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + (qt * 32 + i) * ENC_DH + ks * 16 + h * 8);
-        // pass 1: row maximum (scores are recomputed in pass 2: two MFMAs per tile are cheaper than keeping
-        // the whole row in registers, which would leave one wave per SIMD and nothing to hide latency with)
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + ((qt * 32 + i) * ENC_DH + ks * 16 + h * 8) * 2);
+        // pass 1: row maximum.  Scores are recomputed in pass 2 (two MFMAs per tile) instead of keeping
+        // the 256-wide row in registers, which would leave one wave per SIMD and no latency hiding.
         float m = -1e30f;
-        for (int kt = 0; kt < nkt; ++kt) {
-            f32x16 sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+                f32x16 sc;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kb + (kt * 32 + i) * ENC_DH + ks * 16 + h * 8);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
-            }
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff0), qf[0], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff1), qf[1], sc, 0, 0, 0);
+                if (kt * 32 + 32 <= len) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                m = fmaxf(m, key < len ? sc[r] : -1e30f);
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        m = fmaxf(m, key < len ? sc[r] : -1e30f);
+                    }
+                }
             }
         }
         m = fmaxf(m, __shfl_xor(m, 32));
-        // pass 2: p = 2^(s - m), l = sum p, O += P V
+        // pass 2: the accumulator starts at -m, so the MFMA result is already s - m
         float l = 0.f;
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        for (int kt = 0; kt < nkt; ++kt) {
-            f32x16 sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt < nkt) {
+                f32x16 sc;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kb + (kt * 32 + i) * ENC_DH + ks * 16 + h * 8);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
-            }
+                for (int r = 0; r < 16; ++r) sc[r] = -m;
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff0), qf[0], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff1), qf[1], sc, 0, 0, 0);
+                if (kt * 32 + 32 <= len) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float p = key < len ? __builtin_amdgcn_exp2f(sc[r] - m) : 0.f;
-                sc[r] = p;
-                l += p;
-            }
+                    for (int r = 0; r < 16; ++r) {
+                        sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                        l += sc[r];
+                    }
+                } else {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        sc[r] = key < len ? __builtin_amdgcn_exp2f(sc[r]) : 0.f;
+                        l += sc[r];
+                    }
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s2 + e];
-                const bf16x8 vfrag = *(const bf16x8*)(vb + ((kt * 2 + s2) * 64 + lane) * 8);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vfrag, o, 0, 0, 0);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s2 + e];
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, *(const bf16x8*)(vlds + ((kt * 2 + s2) * 64 + lane) * 16), o, 0, 0, 0);
+                }
             }
         }
         l += __shfl_xor(l, 32);

@@ -23,7 +23,6 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#define MF_QPW 32    // queries per wave (one MFMA tile)
 #define MF_QPB 256   // queries per workgroup
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
@@ -51,13 +50,14 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     return x;
 }
 
-template <int KS, int TR, bool PRE>
-__global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
-    constexpr int QT = 1;
+template <int KS, int TR, bool PRE, int QT>
+__global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
+    constexpr int MF_QPW = 32 * QT;           // queries per wave
+    constexpr int NW = 8 / QT;                // waves per workgroup (256 queries)
     constexpr int DP = KS * 16;               // padded depth (elements)
     constexpr int RB = DP * 2;                // row bytes
     constexpr int TILE_BYTES = TR * RB;
-    constexpr int IPW = TR * KS / 256;        // LDS-DMA instructions per wave per tile
+    constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
     constexpr int NSUB = TR / 32;
     constexpr int PPR = 2 * KS;               // 16-byte pieces per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,22 +129,25 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     for (int c = 0; c < 8; ++c) bc[c] = (int)lds0 + i * RB + (((2 * c) ^ (h ^ (i & 15))) << 4);
 
     if (count > 0) {
+        typedef const __attribute__((address_space(3))) char* lds_cptr;
+        typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+        constexpr int PF = 4;  // A fragments in flight
         issue(0, 0);
         issue(1, 1);
+        issue(2, 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+        __builtin_amdgcn_s_barrier();
         int buf = 0;
-        for (int64_t n = 0; n < count; ++n) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
-            __builtin_amdgcn_s_barrier();
-            {
-                int nb = buf + 2;
-                if (nb >= 3) nb -= 3;
-                issue(n + 2, nb);
-            }
-            const int64_t tile = tile_at(n);
-            typedef const __attribute__((address_space(3))) char* lds_cptr;
-            lds_cptr tb[8];
+        lds_cptr tb[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
+        for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)bc[c];
+        // the first PF fragments of the next 32-row subtile are requested before the current subtile's
+        // epilogue (and, at a tile boundary, right after the barrier), so their LDS latency is covered
+        bf16x8 pre[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+        for (int64_t n = 0; n < count; ++n) {
+            const int64_t tile = tile_at(n);
 #pragma unroll
             for (int sb = 0; sb < NSUB; ++sb) {
                 f32x16 acc[QT];
@@ -152,28 +155,37 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
-                constexpr int PF = 4;  // A fragments in flight
                 bf16x8 av[KS];
 #pragma unroll
-                for (int s = 0; s < PF && s < KS; ++s)
-                    av[s] = *(const __attribute__((address_space(3))) bf16x8*)(tb[s & 7] + sb * 32 * RB + (s >> 3) * 256);
+                for (int s = 0; s < PF; ++s) av[s] = pre[s];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    if (s + PF < KS)
-                        av[s + PF] = *(const __attribute__((address_space(3))) bf16x8*)(tb[(s + PF) & 7] + sb * 32 * RB +
-                                                                                       ((s + PF) >> 3) * 256);
+                    if (s + PF < KS) av[s + PF] = *(lds_frag)(tb[(s + PF) & 7] + sb * 32 * RB + ((s + PF) >> 3) * 256);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], qf[qt][s], acc[qt], 0, 0, 0);
                 }
-                // schedule: PF LDS reads up front, then one MFMA per further read, then the last PF MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+                // schedule: one MFMA per further LDS read, then the last PF MFMAs
 #pragma unroll
                 for (int s = 0; s < KS - PF; ++s) {
                     __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, QT * PF, 0);
+                if (sb + 1 < NSUB) {
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & 7] + (sb + 1) * 32 * RB + (s >> 3) * 256);
+                } else if (n + 1 < count) {
+                    // tile boundary: tile n+1 has landed once at most one younger tile is outstanding
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue(n + 3, buf);  // tile n's buffer is free: every wave has consumed its fragments
+                    buf = buf + 1 == 3 ? 0 : buf + 1;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+                }
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     float m = acc[qt][0];
@@ -199,7 +211,6 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                     }
                 }
             }
-            buf = buf + 1 == 3 ? 0 : buf + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -409,21 +420,25 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         for (int t = tid; t < a.k; t += 256) a.keys_out[(size_t)q * a.k + t] = ek[t];
 }
 
+#ifndef HRS_SCAN_QT
+#define HRS_SCAN_QT 1
+#endif
 template <int KS, int TR>
 static int launch_scan(const MfmaArgs& a, bool pre, hipStream_t st) {
+    constexpr int QT = KS <= 24 ? HRS_SCAN_QT : 1;
     const size_t lds = (size_t)3 * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, QT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false, QT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if (pre)
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true, QT>), dim3(HRS_NUM_CU), dim3(512 / QT), lds, st, a);
     else
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false, QT>), dim3(HRS_NUM_CU), dim3(512 / QT), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
