@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define G_BK 64
 #define G_STAGE_BYTES ((G_BM + G_BN) * G_BK * 2)  // 57344
 
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_PLAIN = 3 };
 
 struct GemmArgs {
     const __bf16* A;     // [M, K]
@@ -302,9 +302,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     issue(1, 1);
     int buf = 0;
     for (int n = 0; n < count; ++n) {
-        // outstanding, oldest first: DMA(n), DMA(n+1), the NST stores of tile n-1 (none before the first tile:
-        // the wait is then merely stricter than needed)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
+        // outstanding, oldest first: DMA(n), DMA(n+1), then the NST stores of tile n-1 (none before the first tile)
+        if (n == 0)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
         __builtin_amdgcn_s_barrier();
         {
             int nb = buf + 2;
@@ -375,6 +377,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                         o[1] = (__bf16)gelu_erf(v1);
                         o[2] = (__bf16)gelu_erf(v2);
                         o[3] = (__bf16)gelu_erf(v3);
+                        *(bf16x4*)(a.C + (size_t)token * a.N + f) = o;
+                    } else if (EPI == EPI_PLAIN) {
+                        o[0] = (__bf16)v0;
+                        o[1] = (__bf16)v1;
+                        o[2] = (__bf16)v2;
+                        o[3] = (__bf16)v3;
                         *(bf16x4*)(a.C + (size_t)token * a.N + f) = o;
                     } else {
                         const float sc = fg == 0 ? a.qscale : 1.0f;
@@ -565,9 +573,9 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, c
 }
 
 // LayerNorm of bf16 rows: lanes 0..47 hold 8 features each (16-byte accesses).
-__global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ in, const float* __restrict__ g,
-                                                   const float* __restrict__ bta, int M, float eps,
-                                                   __bf16* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ in, const __bf16* __restrict__ resid,
+                                                   const float* __restrict__ g, const float* __restrict__ bta, int M,
+                                                   float eps, __bf16* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
@@ -577,10 +585,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ in
     if (on) {
         const bf16x8 r = *(const bf16x8*)(in + (size_t)t * ENC_H + lane * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = (float)r[j];
-            sum += v[j];
+        for (int j = 0; j < 8; ++j) v[j] = (float)r[j];
+        if (resid) {
+            const bf16x8 r2 = *(const bf16x8*)(resid + (size_t)t * ENC_H + lane * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)r2[j];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j];
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -849,18 +861,13 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         at.ctx = cx;
         at.S = S;
         if ((rc = launch_attention(at, Bpad, st))) return rc;
-        memset(&g, 0, sizeof(g));
-        g.M = M;
-        g.S = S;
-        g.A = cx;
-        g.W = L.wo;
-        g.bias = L.bo;
-        g.resid = x;
-        g.C = pre;
-        g.N = H;
-        g.K = H;
-        if ((rc = launch_gemm<EPI_RESID>(ctx, g, st))) return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, L.ln1g, L.ln1b, M, e->cfg.eps, y);
+        gw.A = cx;
+        gw.W = L.wo;
+        gw.bias = L.bo;
+        gw.C = pre;
+        gw.N = H;
+        if ((rc = launch_gemm_ws<EPI_PLAIN>(ctx, gw, st))) return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, x, L.ln1g, L.ln1b, M, e->cfg.eps, y);
         gw.A = y;
         gw.W = L.wi;
         gw.bias = L.bi;
@@ -883,7 +890,7 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         rc = launch_gemm<EPI_RESID>(ctx, g, st);
         if (l == e->cfg.layers - 1) hrs_prof_end(ctx, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, L.ln2g, L.ln2b, M, e->cfg.eps, x);
+        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, (const __bf16*)nullptr, L.ln2g, L.ln2b, M, e->cfg.eps, x);
     }
     hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(384), 0, st, x, lens, S, out_dev);
     HRS_CHECK_HIP(hipGetLastError());
