@@ -20,6 +20,8 @@
 // the V output uses D = A x W^T (feature on the lane: each lane stores 4 consecutive tokens).
 // LDS rows are 128 B; 16-byte piece p of row r is stored at p ^ ((r >> 1) & 7) (permuted on the
 // DMA's source side), which makes the ds_read_b128 fragment reads conflict-free.
+#include <type_traits>
+
 #include "hrs_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -412,6 +414,144 @@ __global__ __launch_bounds__(768) void k_gemm_ws(GemmWsArgs a) {
         gemm_ws_body<EPI, false>(a);
 }
 
+
+// ---- weights-stationary GEMM for the FFN down projection (K = 1536, N = 384) -----------------------
+// The 1.18 MB weight matrix does not fit one CU's registers, a third of it does: a workgroup of four
+// waves (one per SIMD, the whole 512-register file each) holds 128 output features x 1536 depth
+// (96 fragments = 384 registers per lane) and three workgroups cover a row.  Activations stream as
+// 32-token x 512-deep stages (32 KB) through a 4-deep LDS ring by LDS-DMA, three stages in flight;
+// a token tile is finished every third stage.  Output: bias added, bf16, token-major.
+struct GemmDownArgs {
+    const __bf16* A;    // [M, 1536]
+    const __bf16* W;    // [384, 1536]
+    const float* bias;  // [384]
+    __bf16* C;          // [M, 384]
+    int M;
+};
+
+// MFMA with the accumulator and (optionally) the weight fragment in the accumulator half of the
+// register file.  hipcc never picks AGPR source operands by itself, so these are asm; the leading
+// s_nop covers a preceding VALU write of an operand, the caller pads the result's read (mfma_fence).
+__device__ __forceinline__ void mfma_wa(f32x16& acc, const bf16x8& w, const bf16x8& x) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(x));
+}
+__device__ __forceinline__ void mfma_wv(f32x16& acc, const bf16x8& w, const bf16x8& x) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
+}
+__device__ __forceinline__ void mfma_fence(f32x16& acc) {  // 8-pass MFMA result -> any other reader
+    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
+}
+
+__global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
+    constexpr int K = 1536, KC = 512, SPT = 3, KSS = 32, ROWB = KC * 2, STAGE = 32 * ROWB, IPW = 8, NBUF = 4;
+    constexpr int NA = 56;  // weight fragments kept in AGPRs (232 of 256; 16 hold the accumulator)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, i = lane & 31;
+    const int fg = (int)blockIdx.x % 3;
+    const int slice = (int)blockIdx.x / 3, nslices = (int)gridDim.x / 3;
+    const int wfeat = fg * 128 + wv * 32;
+
+    bf16x8 wf[SPT * KSS];
+#pragma unroll
+    for (int s = 0; s < SPT * KSS; ++s) wf[s] = *(const bf16x8*)(a.W + (size_t)(wfeat + i) * K + s * 16 + h * 8);
+    float bz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = a.bias[wfeat + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+    for (int s = 0; s < SPT * KSS; ++s) {
+        if (s < NA)
+            asm volatile("" : "+a"(wf[s]));
+        else
+            asm volatile("" : "+v"(wf[s]));
+    }
+
+    const int tiles = a.M / 32;
+    const int t_begin = (int)((int64_t)tiles * slice / nslices);
+    const int t_end = (int)((int64_t)tiles * (slice + 1) / nslices);
+    const int stages = (t_end - t_begin) * SPT;
+    if (stages > 0) {
+        int srcoff[IPW];
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii) {
+            const int g = (wv * IPW + ii) * 64 + lane;  // 16-byte piece of the stage: 64 per row
+            const int r = g >> 6, p = g & 63;
+            srcoff[ii] = r * (K * 2) + ((p ^ (r & 15)) << 4);
+        }
+        const uint32_t lds0 = lds_addr_of(smem);
+        auto issue = [&](int g) {
+            if (g >= stages) g = stages - 1;
+            const int t = t_begin + g / SPT, kc = g % SPT;
+            const char* base = uniform_ptr((const char*)a.A + ((size_t)t * 32 * K + kc * KC) * 2);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(g % NBUF) * STAGE + wv * (IPW * 1024));
+#pragma unroll
+            for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+        };
+        typedef const __attribute__((address_space(3))) char* lds_cptr;
+        typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+        const int rowoff = (int)lds0 + i * ROWB;
+        const int vx = h ^ (i & 15);
+
+        issue(0);
+        issue(1);
+        issue(2);
+        f32x16 acc;
+        bool stored = false;
+        for (int g = 0; g < stages; ++g) {
+            const int kc = g % SPT;
+            // oldest first: DMA(g), DMA(g+1), DMA(g+2), then the 4 stores of a tile finished in stage g-1
+            if (stored)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW + 4) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(g + 3);
+            stored = false;
+            lds_cptr tb[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(rowoff + (g % NBUF) * STAGE + (((2 * c) ^ vx) << 4));
+            if (kc == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            constexpr int PF = 6;
+            auto run = [&](auto kc_tag) __attribute__((always_inline)) {
+                constexpr int KCI = decltype(kc_tag)::value;
+                bf16x8 av[KSS];
+#pragma unroll
+                for (int s = 0; s < PF; ++s) av[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+#pragma unroll
+                for (int s = 0; s < KSS; ++s) {
+                    if (s + PF < KSS) av[s + PF] = *(lds_frag)(tb[(s + PF) & 7] + ((s + PF) >> 3) * 256);
+                    if (KCI * KSS + s < NA)
+                        mfma_wa(acc, wf[KCI * KSS + s], av[s]);  // D[feature][token]
+                    else
+                        mfma_wv(acc, wf[KCI * KSS + s], av[s]);
+                }
+            };
+            if (kc == 0)
+                run(std::integral_constant<int, 0>{});
+            else if (kc == 1)
+                run(std::integral_constant<int, 1>{});
+            else {
+                run(std::integral_constant<int, 2>{});
+                mfma_fence(acc);
+                const int token = (t_begin + g / SPT) * 32 + i;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[4 * gq + e] + bz[4 * gq + e]);
+                    *(bf16x4*)(a.C + (size_t)token * ENC_H + wfeat + 8 * gq + 4 * h) = o;
+                }
+                stored = true;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- attention -----------------------------------------------------------------------------------
 // One workgroup (4 waves) per (sequence, head); a wave owns 32-query tiles. With S <= 256 the whole
 // score row lives in registers: S^T = K Q^T puts the query on the lane, so the row maximum and sum
@@ -788,6 +928,21 @@ static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
     return HRS_OK;
 }
 
+static int launch_gemm_down(hrs_ctx* ctx, const GemmDownArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    const int lds = 4 * 32 * 1024;
+    if (!attr_set) {
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_down, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    int grid = ctx->num_cu / 3 * 3;
+    const int tiles = g.M / 32;
+    if (tiles * 3 < grid) grid = tiles * 3;
+    hipLaunchKernelGGL(k_gemm_down, dim3(grid), dim3(256), lds, st, g);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
 static int launch_attention(const AttnArgs& a, int B, hipStream_t st) {
     const int nkt = a.S / 32;
     const dim3 grid(B * ENC_HEADS), block(256);
@@ -874,23 +1029,32 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         gw.C = hbuf;
         gw.N = I;
         if ((rc = launch_gemm_ws<EPI_GELU>(ctx, gw, st))) return rc;
-        memset(&g, 0, sizeof(g));
-        g.M = M;
-        g.S = S;
-        g.C = pre;
-        g.N = H;
-        g.A = hbuf;
-        g.W = L.wd;
-        g.bias = L.bd;
-        g.resid = y;
-        g.C = pre;
-        g.N = H;
-        g.K = I;
-        if (l == e->cfg.layers - 1) hrs_prof_begin(ctx, st);
-        rc = launch_gemm<EPI_RESID>(ctx, g, st);
-        if (l == e->cfg.layers - 1) hrs_prof_end(ctx, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, (const __bf16*)nullptr, L.ln2g, L.ln2b, M, e->cfg.eps, x);
+        if (I == 1536) {
+            GemmDownArgs gd;
+            gd.A = hbuf;
+            gd.W = L.wd;
+            gd.bias = L.bd;
+            gd.C = pre;
+            gd.M = M;
+            if (l == e->cfg.layers - 1) hrs_prof_begin(ctx, st);
+            rc = launch_gemm_down(ctx, gd, st);
+            if (l == e->cfg.layers - 1) hrs_prof_end(ctx, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, y, L.ln2g, L.ln2b, M, e->cfg.eps, x);
+        } else {
+            memset(&g, 0, sizeof(g));
+            g.M = M;
+            g.S = S;
+            g.C = pre;
+            g.N = H;
+            g.A = hbuf;
+            g.W = L.wd;
+            g.bias = L.bd;
+            g.resid = y;
+            g.K = I;
+            if ((rc = launch_gemm<EPI_RESID>(ctx, g, st))) return rc;
+            hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, (const __bf16*)nullptr, L.ln2g, L.ln2b, M, e->cfg.eps, x);
+        }
     }
     hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(384), 0, st, x, lens, S, out_dev);
     HRS_CHECK_HIP(hipGetLastError());
