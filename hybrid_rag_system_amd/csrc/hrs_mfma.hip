@@ -18,6 +18,8 @@
 // VGPRs); 64-row corpus tiles (bf16) stream through a 3-deep LDS ring by LDS-DMA and are the A
 // operand, shared by the 8 waves (256 queries per workgroup).  D(32x32) = A(corpus rows) x B(queries)
 // puts the query on the lane, so the filter threshold is one VGPR.
+#include <type_traits>
+
 #include "hrs_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -223,6 +225,146 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
     }
 }
 
+
+// ---- depth 1024 (bge-large class) ----------------------------------------------------------------
+// 32 queries x 1024 depth are 256 registers per lane: more than the arch-VGPR half of the register
+// file, so a workgroup is four waves (one per SIMD, 512 registers each) and most query fragments live
+// in AGPRs, which only an asm MFMA will read as a source operand.  128 queries per workgroup; corpus
+// tiles of 32 rows stream as two 512-deep stages (32 KB) through a 4-deep LDS ring.
+__device__ __forceinline__ void mfma_qa(f32x16& acc, const bf16x8& rows, const bf16x8& q) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(rows), "a"(q));
+}
+__device__ __forceinline__ void mfma_qv(f32x16& acc, const bf16x8& rows, const bf16x8& q) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(rows), "v"(q));
+}
+__device__ __forceinline__ void mfma_result_fence(f32x16& acc) {  // 8-pass MFMA result -> VALU reader
+    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
+    constexpr int DP = 1024, KC = 512, SPT = 2, KSS = 32, ROWB = KC * 2, STAGE = 32 * ROWB, IPW = 8, NBUF = 4, NA = 56;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, i = lane & 31;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int qg = loc % a.nqg;                       // a.nqg: query groups of 128 here (1, 2, 4 or 8)
+    const int nslices = HRS_NUM_CU / a.nqg;
+    const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
+    const int q0 = qg * 128 + wv * 32;
+
+    bf16x8 qf[SPT * KSS];
+#pragma unroll
+    for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + (size_t)(q0 + i) * DP + s * 16 + h * 8);
+    const float tau = PRE ? 0.f : a.tau[q0 + i];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int s = 0; s < SPT * KSS; ++s) {
+        if (s < NA)
+            asm volatile("" : "+a"(qf[s]));
+        else
+            asm volatile("" : "+v"(qf[s]));
+    }
+
+    const int64_t t_begin = a.tiles * slice / nslices;
+    const int64_t t_end = a.tiles * (slice + 1) / nslices;
+    const int64_t count = PRE ? (t_end - t_begin) / a.ss : (t_end - t_begin);
+    const int64_t full_tiles = a.N / 32;
+    auto tile_at = [&](int64_t n) -> int64_t {
+        if (n >= count) n = count - 1;
+        if (!PRE) return t_begin + n;
+        int64_t t = t_begin + n * a.ss + (int64_t)(hash32((uint32_t)(slice * 0x9E3779B1u + n)) % (uint32_t)a.ss);
+        if (t >= full_tiles) t = full_tiles - 1;
+        return t < 0 ? 0 : t;
+    };
+    const int64_t stages = count * SPT;
+    if (stages > 0) {
+        int srcoff[IPW];
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii) {
+            const int g = (wv * IPW + ii) * 64 + lane;
+            const int r = g >> 6, p = g & 63;
+            srcoff[ii] = r * (DP * 2) + ((p ^ (r & 15)) << 4);
+        }
+        const uint32_t lds0 = lds_addr_of(smem);
+        auto issue = [&](int64_t g) {
+            if (g >= stages) g = stages - 1;
+            const int kc = (int)(g % SPT);
+            const char* base = uniform_ptr((const char*)a.shadow + (tile_at(g / SPT) * 32 * DP + kc * KC) * 2);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(g % NBUF) * STAGE + wv * (IPW * 1024));
+#pragma unroll
+            for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+        };
+        typedef const __attribute__((address_space(3))) char* lds_cptr;
+        typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+        const int rowoff = (int)lds0 + i * ROWB;
+        const int vx = h ^ (i & 15);
+        issue(0);
+        issue(1);
+        issue(2);
+        f32x16 acc;
+        for (int64_t g = 0; g < stages; ++g) {
+            const int kc = (int)(g % SPT);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(g + 3);
+            lds_cptr tb[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(rowoff + (int)(g % NBUF) * STAGE + (((2 * c) ^ vx) << 4));
+            if (kc == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            constexpr int PF = 6;
+            auto run = [&](auto kc_tag) __attribute__((always_inline)) {
+                constexpr int KCI = decltype(kc_tag)::value;
+                bf16x8 av[KSS];
+#pragma unroll
+                for (int s = 0; s < PF; ++s) av[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+#pragma unroll
+                for (int s = 0; s < KSS; ++s) {
+                    if (s + PF < KSS) av[s + PF] = *(lds_frag)(tb[(s + PF) & 7] + ((s + PF) >> 3) * 256);
+                    if (KCI * KSS + s < NA)
+                        mfma_qa(acc, av[s], qf[KCI * KSS + s]);  // D[corpus row][query]
+                    else
+                        mfma_qv(acc, av[s], qf[KCI * KSS + s]);
+                }
+            };
+            if (kc == 0) {
+                run(std::integral_constant<int, 0>{});
+            } else {
+                run(std::integral_constant<int, 1>{});
+                mfma_result_fence(acc);
+                float m = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                if (PRE) {
+                    mx = fmaxf(mx, m);
+                } else if (m > tau) {
+                    const int64_t tile = tile_at(g / SPT);
+                    const int q = q0 + i;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[r] > tau) {
+                            const int64_t row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (row < a.N) {
+                                const int pos = atomicAdd(&a.cnt[q], 1);
+                                if (pos < HRS_CAND_CAP)
+                                    a.cand[(size_t)q * HRS_CAND_CAP + pos] =
+                                        ((uint64_t)(~f32_orderable(acc[r])) << 32) | (uint32_t)(row + a.row_offset);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PRE) a.maxima[(size_t)(q0 + i) * HRS_MAX_STREAMS + slice * 2 + h] = mx;
+}
+
 // fp32 [N, D] -> bf16 [Npad, Dpad] (zero padded) and min/max squared row norm. One wave per row.
 __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ C, int64_t N, int D, int64_t Npad,
                                                       int Dpad, __bf16* __restrict__ out,
@@ -252,10 +394,11 @@ __global__ void k_init_stats(unsigned long long* stats) {
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, hipStream_t st) {
     (void)ctx;
     c->Dpad = (c->D + 127) / 128 * 128;
+    if (c->Dpad > 512 && c->Dpad < 1024) c->Dpad = 1024;  // one wide kernel covers (512, 1024]
     c->Npad = (c->N + 63) / 64 * 64 + 64;  // one spare tile: clamped prefetches stay in bounds
     if (c->N == 0) return HRS_OK;
     hipError_t e = hipMalloc((void**)&c->norm_stats, 2 * sizeof(double));
-    if (e == hipSuccess && c->Dpad <= 512) e = hipMalloc((void**)&c->shadow, (size_t)c->Npad * c->Dpad * sizeof(__bf16));
+    if (e == hipSuccess && c->Dpad <= 1024) e = hipMalloc((void**)&c->shadow, (size_t)c->Npad * c->Dpad * sizeof(__bf16));
     if (e != hipSuccess) {
         hrs_set_error("corpus shadow allocation failed: %s", hipGetErrorString(e));
         if (c->norm_stats) hipFree(c->norm_stats);
@@ -447,11 +590,13 @@ static int tile_rows_for(int Dpad) { return Dpad <= 384 ? 64 : 32; }
 
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
                     hipStream_t st) {
-    if (!c->shadow || c->Dpad > 512 || ctx->num_cu != HRS_NUM_CU) {
+    if (!c->shadow || c->Dpad > 1024 || ctx->num_cu != HRS_NUM_CU) {
         // no matrix-core kernel for this shape: the exact scan gives the same answer
         return hrs_launch_exact(ctx, c, Q, B, k, space, nullptr, nullptr, nullptr, keys_out, st);
     }
-    const int Dpad = c->Dpad, KS = Dpad / 16, TR = tile_rows_for(Dpad);
+    const int Dpad = c->Dpad, KS = Dpad / 16;
+    const bool wide = Dpad == 1024;
+    const int TR = wide ? 32 : tile_rows_for(Dpad);
     const int BC = 1024;  // queries per chunk
     // workspace carve
     size_t off = 0;
@@ -479,8 +624,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const int64_t tiles = (c->N + TR - 1) / TR;
     for (int qbase = 0; qbase < B; qbase += BC) {
         const int bc = B - qbase < BC ? B - qbase : BC;
-        const int bpad = bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024);
-        const int nqg = bpad / MF_QPB;
+        const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
+        const int nqg = bpad / (wide ? 128 : MF_QPB);
         const int nslices = HRS_NUM_CU / nqg;
         hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                            bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn));
@@ -517,6 +662,21 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         hrs_prof_end(ctx, st);                                 \
         if (rc) return rc;                                     \
         break;
+        if (wide) {
+            static bool attr_set = false;
+            const int lds = 4 * 32 * 1024;
+            if (!attr_set) {
+                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_mfma_scan_wide<true>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
+            hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt);
+            hrs_prof_begin(ctx, st);
+            hipLaunchKernelGGL(k_mfma_scan_wide<false>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
+            hrs_prof_end(ctx, st);
+            HRS_CHECK_HIP(hipGetLastError());
+        } else
         switch (KS) {
             HRS_SCAN(8, 64)
             HRS_SCAN(16, 64)

@@ -109,6 +109,30 @@ def test_mfma_scan_bit_exact(eng, space):
     corpus.close()
 
 
+@pytest.mark.parametrize("d,b,space", [(1024, 200, "cosine"), (1024, 40, "l2"), (768, 130, "ip")])
+def test_mfma_scan_wide_bit_exact(eng, d, b, space):
+    """Depth (512, 1024]: the four-wave kernel with AGPR-resident query fragments, all query-group counts."""
+    rng = np.random.default_rng(d + b)
+    n, k = 90_003, 10
+    C = _unit(rng, n, d)
+    if space == "ip":
+        C *= rng.uniform(0.7, 1.3, (n, 1)).astype(np.float32)
+    Q = _unit(rng, b, d)
+    for j in range(0, 20):
+        Q[j] = C[j * 1999] + 0.05 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+        Q[j] /= np.linalg.norm(Q[j])
+    C[n - 1] = C[0]
+    want = so.topk_keys(Q, C, k, space)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    got = _keys(keys)
+    assert np.array_equal(got, want), f"mismatching queries: {np.nonzero((got != want).any(1))[0][:10]} stats={st}"
+    assert st["fallback_queries"] <= 3 and st["overflow_queries"] == 0, st
+    corpus.close()
+
+
 def test_mfma_fallback_on_heavy_ties(eng):
     """More exact duplicates of the best row than the re-score window: the proof fails and the
     query is answered by the exact scan, still bit-exact."""
