@@ -4,19 +4,30 @@
 // correctly rounded operation per step, then rounded once to fp32 -- the same operations the CPU
 // oracle performs -- so the (distance, row) order is exact by construction.  The kernel is bound
 // by the HBM stream of the fp32 corpus: one workgroup per CU walks a contiguous slice of rows;
-// 128-row x 64-float segments (32 KB) arrive in a 4-deep LDS ring by LDS-DMA (three segments in
-// flight per CU, counted vmcnt, one barrier per segment).  A thread owns one row of the tile and
-// half of the pass's queries.  The LDS image is lane-linear as the DMA requires; bank conflicts of
-// the per-row reads are avoided by permuting the 16-byte pieces of a row on the SOURCE side
-// (piece p of row r is stored at p ^ (r & 15)).  Nothing in the loop touches global memory except
-// the DMA: the pass's queries are copied to LDS once, candidates live in LDS.
+// 256-row x 32-float segments (32 KB) arrive in a 4-deep LDS ring by LDS-DMA (three segments in
+// flight per CU, counted vmcnt, one barrier per segment).  A thread owns one row of the tile: the
+// per-row fp64 fma chain is latency bound, so a segment is wide in rows (256 independent chains, one
+// wave on every SIMD) and short in depth.  The LDS image is lane-linear as the DMA requires; bank
+// conflicts of the per-row reads are avoided by permuting the 16-byte pieces of a row on the SOURCE
+// side (piece p of row r is stored at p ^ ESWZ(r)).  Nothing in the loop touches global memory
+// except the DMA: the pass's queries are copied to LDS once, candidates live in LDS.
 #include "hrs_internal.h"
 
-#define ER 128   // rows per tile
-#define EDC 64   // floats per row segment
+#ifndef ER
+#define ER 256   // rows per tile
+#endif
+#ifndef EDC
+#define EDC 32   // floats per row segment
+#endif
+#ifndef ENBUF
 #define ENBUF 4  // ring depth
+#endif
+#define EPP (EDC / 4)             // 16-byte pieces per row segment = DMA lanes per row
+#define ERPI (64 / EPP)           // rows per DMA instruction
+#define ESWZ(r) (((r) / (16 / EPP)) & (EPP - 1))  // piece p of row r is stored at p ^ ESWZ(r)
 #define ESEG_BYTES (ER * EDC * 4)
-#define EIPW 8   // LDS-DMA instructions per wave per segment (32 KB / 1 KB / 4 waves)
+#define EIPW (ESEG_BYTES / 4096)  // LDS-DMA instructions per wave per segment (1 KB each, 4 waves)
+#define ESLOTS (256 / ER)         // query slots per row (threads that share a row, one query subset each)
 #define EQ_FLOATS 2048  // fp32 query staging: BQ * D <= 2048
 
 struct ExactArgs {
@@ -36,7 +47,8 @@ struct ExactArgs {
 
 template <int SPACE, int BQ>
 __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
-    constexpr int NQT = BQ >= 2 ? BQ / 2 : 1;  // queries per thread (two query slots per row)
+    constexpr int NQT = BQ > ESLOTS ? BQ / ESLOTS : 1;  // queries per thread
+    constexpr int NSL = BQ < ESLOTS ? BQ : ESLOTS;      // query slots in use
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: ring [ENBUF][ESEG_BYTES] | qf32 [EQ_FLOATS] | qbuf [2][BQ][EDC] double | cand [BQ][CB] | misc
     char* ring = smem;
@@ -52,7 +64,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row_t = tid & (ER - 1);   // this thread's row inside a tile
-    const int qslot = tid >> 7;         // 0 or 1
+    const int qslot = tid / ER;
     int nq = a.nq_dev ? *a.nq_dev : a.nq;
     if (nq > a.nq) nq = a.nq;
     if (nq <= 0) return;
@@ -96,8 +108,8 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
         int fastoff[EIPW];
 #pragma unroll
         for (int i = 0; i < EIPW; ++i) {
-            const int r = wv * 32 + i * 4 + (lane >> 4);
-            fastoff[i] = (r * D + (((lane & 15) ^ (r & 15)) << 2)) * 4;
+            const int r = wv * (ER / 4) + i * ERPI + lane / EPP;
+            fastoff[i] = (r * D + (((lane & (EPP - 1)) ^ ESWZ(r)) << 2)) * 4;
         }
         auto issue_dma = [&](int64_t step) {
             if (step >= steps) step = steps - 1;  // keep the vmcnt bookkeeping uniform at the tail
@@ -113,9 +125,9 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < EIPW; ++i) {
-                    int r = wv * 32 + i * 4 + (lane >> 4);
-                    const int p = lane & 15;
-                    int sp = p ^ (r & 15);
+                    int r = wv * (ER / 4) + i * ERPI + lane / EPP;
+                    const int p = lane & (EPP - 1);
+                    int sp = p ^ ESWZ(r);
                     if (sp >= wpieces) sp = 0;
                     if (r >= rows_left) r = (int)rows_left - 1;
                     glds16_asm(base, (r * D + sp * 4) * 4, dst + i * 1024);
@@ -127,27 +139,26 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
         double ncacc = 0.0;
         if (steps > 0) {
             stage_q(0, 0);
-            issue_dma(0);
-            issue_dma(1);
-            issue_dma(2);
+#pragma unroll
+            for (int g = 0; g < ENBUF - 1; ++g) issue_dma(g);
         }
         for (int64_t step = 0; step < steps; ++step) {
             const int ch = (int)(step % nchunks);
-            // segments step+1 and step+2 may stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * EIPW) : "memory");
+            // segments step+1 .. step+ENBUF-2 may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ENBUF - 2) * EIPW) : "memory");
             __syncthreads();
-            issue_dma(step + 3);
+            issue_dma(step + ENBUF - 1);
             if (step + 1 < steps) stage_q((int)((step + 1) % nchunks), (int)((step + 1) & 1));
             if (ch == 0) {
 #pragma unroll
                 for (int b = 0; b < NQT; ++b) acc[b] = 0.0;
                 ncacc = 0.0;
             }
-            if (BQ >= 2 || qslot == 0) {
+            if (qslot < NSL) {
                 const int pieces = min(EDC, D - ch * EDC) >> 2;
                 const char* rowp = ring + (step % ENBUF) * ESEG_BYTES + row_t * (EDC * 4);
                 const double* qb = qbuf + (step & 1) * BQ * EDC;
-                const int sw = row_t & 15;
+                const int sw = ESWZ(row_t);
                 auto piece = [&](int s) {
                     const float4 cv = *(const float4*)(rowp + ((s ^ sw) << 4));
                     const double c0 = (double)cv.x, c1 = (double)cv.y, c2 = (double)cv.z, c3 = (double)cv.w;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                     }
 #pragma unroll
                     for (int b = 0; b < NQT; ++b) {
-                        const double* qp = qb + (BQ >= 2 ? qslot + 2 * b : 0) * EDC + s * 4;
+                        const double* qp = qb + (qslot + NSL * b) * EDC + s * 4;
                         const double q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
                         if (SPACE == HRS_SPACE_L2) {
                             const double d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
@@ -186,13 +197,13 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             if (ch == nchunks - 1) {
                 const int64_t tile = tile_begin + step / nchunks;
                 const int64_t row = tile * ER + row_t;
-                bool live = row < a.N && (BQ >= 2 || qslot == 0);
+                bool live = row < a.N && qslot < NSL;
                 if (live && a.mask) live = a.mask[row] != 0;
                 if (live) {
                     const uint32_t grow = (uint32_t)(row + a.row_offset);
 #pragma unroll
                     for (int b = 0; b < NQT; ++b) {
-                        const int qb_i = BQ >= 2 ? qslot + 2 * b : 0;
+                        const int qb_i = qslot + NSL * b;
                         double d;
                         if (SPACE == HRS_SPACE_L2) {
                             d = acc[b];

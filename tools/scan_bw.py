@@ -5,7 +5,8 @@ import torch
 from hybrid_rag_system_amd.engine import Engine
 eng = Engine(0)
 total = 8 << 30
-for D in (64, 128, 256, 384, 512, 1024):
+dims = [int(x) for x in sys.argv[1:]] or [64, 128, 256, 384, 512, 1024]
+for D in dims:
     n = total // (4 * D)
     m = torch.empty((n, D), dtype=torch.float32, device='cuda')
     for r0 in range(0, n, 1 << 20):
