@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhrs.so")
 
 SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+SHADOWS = {"none": 0, "bf16": 1, "i8": 2, "auto": 3}
 MODE_AUTO, MODE_EXACT, MODE_MFMA = 0, 1, 2
 MAX_K = 128
 PAD_KEY = 0xFFFFFFFFFFFFFFFF
@@ -21,6 +22,7 @@ EXPORTS = [
     "hrs_ctx_destroy",
     "hrs_corpus_register",
     "hrs_corpus_release",
+    "hrs_corpus_shadow",
     "hrs_corpus_stats",
     "hrs_score_topk",
     "hrs_score_stats",
@@ -69,6 +71,7 @@ def lib():
             "hrs_ctx_destroy": ([vp], i32),
             "hrs_corpus_register": ([vp, vp, i64, i32, i64, vp, C.POINTER(vp)], i32),
             "hrs_corpus_release": ([vp, vp], i32),
+            "hrs_corpus_shadow": ([vp, vp, i32, vp], i32),
             "hrs_corpus_stats": ([vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)], i32),
             "hrs_score_topk": ([vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], i32),
             "hrs_score_stats": ([vp, vp, C.POINTER(i64)], i32),

@@ -136,7 +136,7 @@ extern "C" int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, 
     c->N = N;
     c->D = D;
     c->row_offset = row_offset;
-    int rc = hrs_build_shadow(ctx, c, (hipStream_t)stream);
+    int rc = hrs_build_shadow(ctx, c, HRS_SHADOW_AUTO, (hipStream_t)stream);
     if (rc) {
         delete c;
         return rc;
@@ -149,10 +149,17 @@ extern "C" int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* c) {
     if (!c) return HRS_OK;
     if (ctx) hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    if (c->shadow) hipFree(c->shadow);
-    if (c->norm_stats) hipFree(c->norm_stats);
+    hrs_free_shadow(c);
     delete c;
     return HRS_OK;
+}
+
+extern "C" int hrs_corpus_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, void* stream) {
+    HRS_REQUIRE(ctx && c, "hrs_corpus_shadow: null handle");
+    HRS_REQUIRE(kind >= HRS_SHADOW_NONE && kind <= HRS_SHADOW_AUTO, "hrs_corpus_shadow: unknown kind %d", kind);
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    HRS_CHECK_HIP(hipDeviceSynchronize());  // nothing may still read the shadow being replaced
+    return hrs_build_shadow(ctx, c, kind, (hipStream_t)stream);
 }
 
 extern "C" int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* c, void* stream, double* mn, double* mx) {

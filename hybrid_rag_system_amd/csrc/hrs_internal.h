@@ -57,10 +57,13 @@ struct hrs_corpus {
     int64_t N = 0;
     int D = 0;
     int64_t row_offset = 0;
-    __bf16* shadow = nullptr;  // owned: bf16 [Npad, Dpad], zero padded
+    int kind = 0;              // hrs_shadow_kind of the scan shadow
+    void* shadow = nullptr;    // owned: bf16 or int8 [Npad, Dpad], zero padded
+    float2* group_pre = nullptr;   // owned (int8 shadow): per 32-row group (scale, M_g); then, in the same
+    float2* group_main = nullptr;  // allocation, (1 / scale, M_g)
     int64_t Npad = 0;
     int Dpad = 0;
-    double* norm_stats = nullptr;  // owned: [2] = {min |c|^2, max |c|^2} as doubles
+    double* norm_stats = nullptr;  // owned: {min |c|^2, max |c|^2} as doubles
 };
 
 struct hrs_postings {
@@ -137,4 +140,5 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st);
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
                     hipStream_t st);
-int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, hipStream_t st);
+int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st);
+void hrs_free_shadow(hrs_corpus* c);

@@ -24,14 +24,30 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+
+// The scan runs on one of two shadows of the corpus.  bf16: v_mfma_f32_32x32x16_bf16, 16 depth
+// elements per k-step.  int8: v_mfma_i32_32x32x32_i8, 32 depth elements per k-step, twice the rate and
+// half the bytes; each 32-row group g carries one fp32 scale s_g (row value = s_g * int8), queries one
+// scale each.  With e = I8_EMAX, q = sq (qi + eq), c = s_g (ci + ec), |eq|, |ec| <= e:
+//     q.c / sq  <=  s_g * (qi.ci + K_q + M_g),   K_q = e |qi|_1 + e^2 D,   M_g = e max_rows |ci|_1
+// and the int8 kernel filters, records and ranks by that UPPER BOUND of the scaled score, so a row it
+// does not record is provably below the threshold and no further error term enters the acceptance test.
+// Either way a fragment is 16 bytes per lane and a row is KS * 32 bytes, so the addressing is shared.
+template <bool I8> struct scan_types { typedef bf16x8 frag; typedef f32x16 acc; };
+template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
+#define I8_EMAX 0.5001   // bound of |x / scale - rint(x / scale)| incl. the fp32 division error
 
 #define MF_QPB 256   // queries per workgroup
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
 
 struct MfmaArgs {
-    const __bf16* shadow;  // [Npad][Dpad]
-    const __bf16* qb;      // [Bpad][Dpad]
+    const char* shadow;    // [Npad][KS * 32 bytes]
+    const char* qb;        // [Bpad][KS * 32 bytes]
+    const float2* group;   // int8 only, per 32-row group: (s_g, M_g) for PRE, (1 / s_g, M_g) for MAIN
+    const float* kq;       // int8 only, per query: K_q
     int64_t N;
     int64_t tiles;         // ceil(N / TR)
     int64_t row_offset;
@@ -52,16 +68,24 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     return x;
 }
 
-template <int KS, int TR, bool PRE, int QT>
+template <int KS, int TR, bool PRE, int QT, bool I8>
 __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
+    typedef typename scan_types<I8>::frag frag_t;
+    typedef typename scan_types<I8>::acc acc_t;
     constexpr int MF_QPW = 32 * QT;           // queries per wave
     constexpr int NW = 8 / QT;                // waves per workgroup (256 queries)
-    constexpr int DP = KS * 16;               // padded depth (elements)
-    constexpr int RB = DP * 2;                // row bytes
+    constexpr int RB = KS * 32;               // row bytes
     constexpr int TILE_BYTES = TR * RB;
     constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
     constexpr int NSUB = TR / 32;
     constexpr int PPR = 2 * KS;               // 16-byte pieces per row
+    // Bank-conflict-free row reads need an XOR permutation of the pieces of a row that depends on the
+    // row: 4 bits (r & 15) when the row is a multiple of 256 bytes, else 3 bits ((r >> 1) & 7) for rows
+    // that are an odd multiple of 128 bytes (adjacent rows already differ by half the bank window).
+    constexpr int SWB = (PPR % 16 == 0) ? 4 : 3;
+    constexpr int NB = 1 << (SWB - 1);        // per-lane fragment base addresses
+    constexpr int FSTEP = 16 << SWB;          // bytes between fragments NB k-steps apart
+    static_assert(PPR % 8 == 0, "row bytes must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -74,18 +98,19 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
     const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
     const int q0 = qg * MF_QPB + wv * MF_QPW;
 
-    bf16x8 qf[QT][KS];
+    frag_t qf[QT][KS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            qf[qt][s] = *(const bf16x8*)(a.qb + (size_t)(q0 + qt * 32 + i) * DP + s * 16 + h * 8);
+            qf[qt][s] = *(const frag_t*)(a.qb + (size_t)(q0 + qt * 32 + i) * RB + s * 32 + h * 16);
 
-    float tau[QT];
+    float tau[QT], kq[QT];
     float mx[QT][NSUB];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         tau[qt] = PRE ? 0.f : a.tau[q0 + qt * 32 + i];
+        kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) mx[qt][sb] = -__builtin_inff();
     }
@@ -95,6 +120,8 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]));
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
@@ -115,57 +142,84 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
     for (int ii = 0; ii < IPW; ++ii) {
         const int g = (wv * IPW + ii) * 64 + lane;
         const int r = g / PPR, p = g % PPR;
-        srcoff[ii] = r * RB + ((p ^ (r & 15)) << 4);
+        srcoff[ii] = r * RB + ((p ^ (SWB == 4 ? (r & 15) : ((r >> 1) & 7))) << 4);
     }
     const uint32_t lds0 = lds_addr_of(smem);
     auto issue = [&](int64_t n, int buf) {
-        const char* base = uniform_ptr((const char*)a.shadow + tile_at(n) * (int64_t)TILE_BYTES);
+        const char* base = uniform_ptr(a.shadow + tile_at(n) * (int64_t)TILE_BYTES);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + wv * (IPW * 1024));
 #pragma unroll
         for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
     };
-    // read side: k-step s of row i wants piece 2s+h, stored at (2s+h) ^ (i&15).  With v = h ^ (i&15)
-    // the low four bits are ((2s)&15) ^ v: eight per-lane bases, everything else is an immediate.
-    int bc[8];
+    // read side: k-step s of row i wants piece 2s+h, stored at (2s+h) ^ w(i).  With v = h ^ w the low
+    // SWB bits are ((2s) & mask) ^ v: NB per-lane bases, everything else is an immediate.
+    int bc[NB];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) bc[c] = (int)lds0 + i * RB + (((2 * c) ^ (h ^ (i & 15))) << 4);
+    for (int c = 0; c < NB; ++c) bc[c] = (int)lds0 + i * RB + (((2 * c) ^ (h ^ (SWB == 4 ? (i & 15) : ((i >> 1) & 7)))) << 4);
 
     if (count > 0) {
         typedef const __attribute__((address_space(3))) char* lds_cptr;
-        typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+        typedef const __attribute__((address_space(3))) frag_t* lds_frag;
         constexpr int PF = 4;  // A fragments in flight
+        // int8: the group terms of a tile come by scalar load (its counter is lgkmcnt, so the LDS-DMA
+        // ring is left alone), requested one tile ahead
+        float2 sc[NSUB], scn[NSUB];
+        auto scale_load = [&](int64_t tile) __attribute__((always_inline)) {
+            const char* p = uniform_ptr(a.group + tile * NSUB);
+            if (NSUB == 2) {
+                float4 v;
+                asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p));
+                scn[0] = make_float2(v.x, v.y);
+                scn[NSUB - 1] = make_float2(v.z, v.w);
+            } else {
+                asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(scn[0]) : "s"(p));
+            }
+        };
+        if (I8) scale_load(tile_at(0));
         issue(0, 0);
         issue(1, 1);
         issue(2, 2);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0;
-        lds_cptr tb[8];
+        lds_cptr tb[NB];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)bc[c];
+        for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)bc[c];
         // the first PF fragments of the next 32-row subtile are requested before the current subtile's
         // epilogue (and, at a tile boundary, right after the barrier), so their LDS latency is covered
-        bf16x8 pre[PF];
+        frag_t pre[PF];
 #pragma unroll
-        for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+        for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (s / NB) * FSTEP);
         for (int64_t n = 0; n < count; ++n) {
             const int64_t tile = tile_at(n);
+            if (I8) {
+#pragma unroll
+                for (int sb = 0; sb < NSUB; ++sb) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(scn[sb].x), "+s"(scn[sb].y));
+                    sc[sb] = scn[sb];
+                }
+                scale_load(tile_at(n + 1));
+            }
 #pragma unroll
             for (int sb = 0; sb < NSUB; ++sb) {
-                f32x16 acc[QT];
+                acc_t acc[QT];
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
-                bf16x8 av[KS];
+                    for (int r = 0; r < 16; ++r) acc[qt][r] = 0;
+                frag_t av[KS];
 #pragma unroll
                 for (int s = 0; s < PF; ++s) av[s] = pre[s];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    if (s + PF < KS) av[s + PF] = *(lds_frag)(tb[(s + PF) & 7] + sb * 32 * RB + ((s + PF) >> 3) * 256);
+                    if (s + PF < KS) av[s + PF] = *(lds_frag)(tb[(s + PF) & (NB - 1)] + sb * 32 * RB + ((s + PF) / NB) * FSTEP);
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], qf[qt][s], acc[qt], 0, 0, 0);
+                    for (int qt = 0; qt < QT; ++qt) {
+                        if constexpr (I8)
+                            acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], qf[qt][s], acc[qt], 0, 0, 0);
+                        else
+                            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], qf[qt][s], acc[qt], 0, 0, 0);
+                    }
                 }
                 // schedule: one MFMA per further LDS read, then the last PF MFMAs
 #pragma unroll
@@ -176,7 +230,7 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, QT * PF, 0);
                 if (sb + 1 < NSUB) {
 #pragma unroll
-                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & 7] + (sb + 1) * 32 * RB + (s >> 3) * 256);
+                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
                 } else if (n + 1 < count) {
                     // tile boundary: tile n+1 has landed once at most one younger tile is outstanding
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
@@ -184,31 +238,55 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
                     issue(n + 3, buf);  // tile n's buffer is free: every wave has consumed its fragments
                     buf = buf + 1 == 3 ? 0 : buf + 1;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
+                    for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
 #pragma unroll
-                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (s / NB) * FSTEP);
                 }
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
-                    float m = acc[qt][0];
+                    auto append = [&](int r, float score) __attribute__((always_inline)) {
+                        const int64_t row = tile * TR + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < a.N) {
+                            const int q = q0 + qt * 32 + i;
+                            const int pos = atomicAdd(&a.cnt[q], 1);
+                            if (pos < HRS_CAND_CAP)
+                                a.cand[(size_t)q * HRS_CAND_CAP + pos] =
+                                    ((uint64_t)(~f32_orderable(score)) << 32) | (uint32_t)(row + a.row_offset);
+                        }
+                    };
+                    if constexpr (I8) {
+                        int m = acc[qt][0];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qt][r]);
-                    if (PRE) {
-                        mx[qt][sb] = fmaxf(mx[qt][sb], m);
-                    } else if (m > tau[qt]) {
-                        const int q = q0 + qt * 32 + i;
+                        for (int r = 1; r < 16; ++r) m = max(m, acc[qt][r]);
+                        if (PRE) {
+                            mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + kq[qt] + sc[sb].y) * sc[sb].x);  // .x = s_g
+                        } else {
+                            // s_g (acc + K_q + M_g) > tau  <=>  acc > tau / s_g - K_q - M_g; the threshold is
+                            // pushed down by more than the rounding of these few operations, so that no
+                            // qualifying row is dropped
+                            float tf = tau[qt] * sc[sb].x;  // .x = 1 / s_g
+                            tf -= fabsf(tf) * 3e-7f;
+                            tf = tf - kq[qt] - sc[sb].y - 0.5f;
+                            const int ti = (int)floorf(fminf(fmaxf(tf, -2.1e9f), 2.1e9f));
+                            if (m > ti) {
+                                // s_g again, from its reciprocal: no vector load may appear in this loop (its
+                                // wait would drain the DMA ring); the acceptance test allows for the rounding
+                                const float gs = 1.0f / sc[sb].x;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if (acc[qt][r] > tau[qt]) {
-                                const int64_t row = tile * TR + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                if (row < a.N) {
-                                    const int pos = atomicAdd(&a.cnt[q], 1);
-                                    if (pos < HRS_CAND_CAP)
-                                        a.cand[(size_t)q * HRS_CAND_CAP + pos] =
-                                            ((uint64_t)(~f32_orderable(acc[qt][r])) << 32) |
-                                            (uint32_t)(row + a.row_offset);
-                                }
+                                for (int r = 0; r < 16; ++r)
+                                    if (acc[qt][r] > ti) append(r, ((float)acc[qt][r] + kq[qt] + sc[sb].y) * gs);
                             }
+                        }
+                    } else {
+                        float m = acc[qt][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qt][r]);
+                        if (PRE) {
+                            mx[qt][sb] = fmaxf(mx[qt][sb], m);
+                        } else if (m > tau[qt]) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (acc[qt][r] > tau[qt]) append(r, acc[qt][r]);
                         }
                     }
                 }
@@ -257,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
 
     bf16x8 qf[SPT * KSS];
 #pragma unroll
-    for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + (size_t)(q0 + i) * DP + s * 16 + h * 8);
+    for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + ((size_t)(q0 + i) * DP + s * 16 + h * 8) * 2);
     const float tau = PRE ? 0.f : a.tau[q0 + i];
     float mx = -__builtin_inff();
 #pragma unroll
@@ -386,32 +464,156 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
     }
 }
 
+
+// fp32 [N, D] -> int8 [Npad, Dpad] with one scale per 32-row group (s_g = max |c| of the group / 127,
+// value = rint(c / s_g)) and the group's pairs (s_g, M_g), (1 / s_g, M_g).  One workgroup per group.
+// Also min/max squared row norm (stats[0..1], doubles).
+__global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict__ C, int64_t N, int D, int Dpad,
+                                                         int8_t* __restrict__ out, float2* __restrict__ pre_pair,
+                                                         float2* __restrict__ main_pair,
+                                                         unsigned long long* __restrict__ stats) {
+    __shared__ float red[4];
+    __shared__ int l1max;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t g = blockIdx.x, r0 = g * 32;
+    if (threadIdx.x == 0) l1max = 0;
+    float mxv = 0.f;
+    for (int rr = wv; rr < 32; rr += 4) {
+        const int64_t r = r0 + rr;
+        if (r >= N) break;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = *(const float4*)(C + r * D + c);
+            mxv = fmaxf(mxv, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+    if (lane == 0) red[wv] = mxv;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float gs = gmax / 127.0f;
+    for (int rr = wv; rr < 32; rr += 4) {
+        const int64_t r = r0 + rr;
+        int l1 = 0;
+        double ss = 0.0;
+        for (int c = lane * 4; c < Dpad; c += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < N && c < D) v = *(const float4*)(C + r * D + c);
+            ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            if (gs > 0.f) {
+                q0 = (int)rintf(v.x / gs);
+                q1 = (int)rintf(v.y / gs);
+                q2 = (int)rintf(v.z / gs);
+                q3 = (int)rintf(v.w / gs);
+            }
+            l1 += abs(q0) + abs(q1) + abs(q2) + abs(q3);
+            const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) |
+                                    ((uint32_t)(q3 & 0xff) << 24);
+            *(uint32_t*)(out + r * Dpad + c) = packed;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            l1 += __shfl_xor(l1, o);
+            ss += __shfl_xor(ss, o);
+        }
+        if (lane == 0 && r < N) {
+            atomicMin(&stats[0], (unsigned long long)__double_as_longlong(ss));
+            atomicMax(&stats[1], (unsigned long long)__double_as_longlong(ss));
+            atomicMax(&l1max, l1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mg = (float)I8_EMAX * (float)l1max * 1.000001f + 0.01f;  // rounded up
+        // an all-zero group scores exactly 0: a huge reciprocal keeps it out for any positive threshold
+        pre_pair[g] = make_float2(gs, mg);
+        main_pair[g] = make_float2(gs > 0.f ? 1.0f / gs : 1e30f, mg);
+    }
+}
+
 __global__ void k_init_stats(unsigned long long* stats) {
     stats[0] = (unsigned long long)__double_as_longlong(1e300);
     stats[1] = 0ull;
 }
 
-int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, hipStream_t st) {
+void hrs_free_shadow(hrs_corpus* c) {
+    if (c->shadow) (void)hipFree(c->shadow);
+    if (c->group_pre) (void)hipFree(c->group_pre);
+    if (c->norm_stats) (void)hipFree(c->norm_stats);
+    c->shadow = nullptr;
+    c->group_pre = c->group_main = nullptr;
+    c->norm_stats = nullptr;
+    c->kind = HRS_SHADOW_NONE;
+}
+
+// (Re)build the scan shadow of a corpus: int8 with group scales (default) or bf16.
+int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st) {
     (void)ctx;
-    c->Dpad = (c->D + 127) / 128 * 128;
-    if (c->Dpad > 512 && c->Dpad < 1024) c->Dpad = 1024;  // one wide kernel covers (512, 1024]
+    hrs_free_shadow(c);
+    if (kind == HRS_SHADOW_AUTO) kind = c->D <= 512 ? HRS_SHADOW_I8 : HRS_SHADOW_BF16;
     c->Npad = (c->N + 63) / 64 * 64 + 64;  // one spare tile: clamped prefetches stay in bounds
-    if (c->N == 0) return HRS_OK;
+    if (c->N == 0 || kind == HRS_SHADOW_NONE) return HRS_OK;
+    c->Dpad = (c->D + 127) / 128 * 128;
+    if (kind == HRS_SHADOW_I8) {
+        if (c->Dpad > 512) c->Dpad = c->Dpad <= 768 ? 768 : 1024;
+    } else {
+        if (c->Dpad > 512 && c->Dpad < 1024) c->Dpad = 1024;  // one wide kernel covers (512, 1024]
+    }
+    if (c->D > 1024) return HRS_OK;  // deeper rows: exact scan only
+    const size_t esz = kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
+    const int64_t groups = c->Npad / 32;
     hipError_t e = hipMalloc((void**)&c->norm_stats, 2 * sizeof(double));
-    if (e == hipSuccess && c->Dpad <= 1024) e = hipMalloc((void**)&c->shadow, (size_t)c->Npad * c->Dpad * sizeof(__bf16));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->shadow, (size_t)c->Npad * c->Dpad * esz);
+    if (e == hipSuccess && kind == HRS_SHADOW_I8) e = hipMalloc((void**)&c->group_pre, (size_t)(2 * groups + 64) * sizeof(float2));
     if (e != hipSuccess) {
         hrs_set_error("corpus shadow allocation failed: %s", hipGetErrorString(e));
-        if (c->norm_stats) hipFree(c->norm_stats);
-        c->norm_stats = nullptr;
+        hrs_free_shadow(c);
         return HRS_ERR_NOMEM;
     }
     hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(1), 0, st, (unsigned long long*)c->norm_stats);
-    if (c->shadow) {
+    if (kind == HRS_SHADOW_I8) {
+        c->group_main = c->group_pre + groups + 32;
+        hipLaunchKernelGGL(k_build_shadow_i8, dim3((unsigned)groups), dim3(256), 0, st, c->C, c->N, c->D, c->Dpad,
+                           (int8_t*)c->shadow, c->group_pre, c->group_main, (unsigned long long*)c->norm_stats);
+    } else {
         hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)((c->Npad + 3) / 4)), dim3(256), 0, st, c->C, c->N, c->D,
-                           c->Npad, c->Dpad, c->shadow, (unsigned long long*)c->norm_stats);
+                           c->Npad, c->Dpad, (__bf16*)c->shadow, (unsigned long long*)c->norm_stats);
     }
     HRS_CHECK_HIP(hipGetLastError());
+    c->kind = kind;
     return HRS_OK;
+}
+
+// Queries fp32 [B, D] -> int8 [Bpad, Dpad] with one scale per query (max |q| / 127); squared norms in
+// fp64, the scale and K_q = e |q_int|_1 + e^2 D of the error bound.  One wave per query.
+__global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ Q, int B, int D, int Bpad, int Dpad,
+                                                      int8_t* __restrict__ qb, double* __restrict__ qn2,
+                                                      float* __restrict__ qscale, float* __restrict__ kq) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Bpad) return;
+    float mxv = 0.f;
+    if (q < B)
+        for (int c = lane; c < D; c += 64) mxv = fmaxf(mxv, fabsf(Q[(size_t)q * D + c]));
+    for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
+    const float sq = mxv / 127.0f;
+    double ss = 0.0;
+    int l1 = 0;
+    for (int c = lane; c < Dpad; c += 64) {
+        const float v = (q < B && c < D) ? Q[(size_t)q * D + c] : 0.f;
+        const int qi = sq > 0.f ? (int)rintf(v / sq) : 0;
+        qb[(size_t)q * Dpad + c] = (int8_t)qi;
+        l1 += abs(qi);
+        ss += (double)v * (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o);
+        l1 += __shfl_xor(l1, o);
+    }
+    if (lane == 0) {
+        qn2[q] = ss;
+        qscale[q] = sq;
+        kq[q] = ((float)I8_EMAX * (float)l1 + (float)(I8_EMAX * I8_EMAX) * (float)D) * 1.000001f + 0.01f;  // rounded up
+    }
 }
 
 // Queries fp32 [B, D] -> bf16 [Bpad, Dpad] (zero padded), squared norms in fp64. One wave per query.
@@ -462,8 +664,10 @@ struct SelectArgs {
     const uint64_t* cand;
     const float* tau;
     const double* qn2;
-    const double* norm_stats;
+    const double* norm_stats;  // min/max |c|^2
     double eps_rel;
+    const float* qscale;       // int8 shadow only (else null): per-query scale; candidate scores are then
+                               // upper bounds of score / scale
     uint64_t* keys_out;  // [B][k]
     int32_t* qlist;      // queue of queries for the exact fallback
     int32_t* nflag;
@@ -538,7 +742,15 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
             // best approximate score of anything that was not re-scored
             const float A = c > R ? orderable_f32(~(uint32_t)(s[R] >> 32)) : a.tau[ql];
             const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
-            const double sb = (double)A + a.eps_rel * sqrt(qn) * sqrt(ncmax) + 1e-30;
+            double sb;
+            if (a.qscale) {
+                // A bounds score / scale of every row that was not re-scored; allow for the fp32
+                // roundings made while it was computed
+                const double v = (double)A * (double)a.qscale[ql];
+                sb = v + 2e-6 * fabs(v) + 1e-6 * sqrt(qn) * sqrt(ncmax) + 1e-30;
+            } else {
+                sb = (double)A + a.eps_rel * sqrt(qn) * sqrt(ncmax) + 1e-30;
+            }
             double dmin;
             if (SPACE == HRS_SPACE_L2)
                 dmin = qn + ncmin - 2.0 * sb;
@@ -563,40 +775,37 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         for (int t = tid; t < a.k; t += 256) a.keys_out[(size_t)q * a.k + t] = ek[t];
 }
 
-#ifndef HRS_SCAN_QT
-#define HRS_SCAN_QT 1
-#endif
-template <int KS, int TR>
-static int launch_scan(const MfmaArgs& a, bool pre, hipStream_t st) {
-    constexpr int QT = KS <= 24 ? HRS_SCAN_QT : 1;
+template <int KS, int TR, bool I8>
+static int launch_scan(MfmaArgs a, bool pre, const hrs_corpus* c, hipStream_t st) {
     const size_t lds = (size_t)3 * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, QT>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, 1, I8>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false, QT>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false, 1, I8>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    a.group = pre ? c->group_pre : c->group_main;
     if (pre)
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true, QT>), dim3(HRS_NUM_CU), dim3(512 / QT), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true, 1, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     else
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false, QT>), dim3(HRS_NUM_CU), dim3(512 / QT), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false, 1, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
 
-static int tile_rows_for(int Dpad) { return Dpad <= 384 ? 64 : 32; }
 
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
                     hipStream_t st) {
-    if (!c->shadow || c->Dpad > 1024 || ctx->num_cu != HRS_NUM_CU) {
+    if (!c->shadow || ctx->num_cu != HRS_NUM_CU) {
         // no matrix-core kernel for this shape: the exact scan gives the same answer
         return hrs_launch_exact(ctx, c, Q, B, k, space, nullptr, nullptr, nullptr, keys_out, st);
     }
-    const int Dpad = c->Dpad, KS = Dpad / 16;
-    const bool wide = Dpad == 1024;
-    const int TR = wide ? 32 : tile_rows_for(Dpad);
+    const bool i8 = c->kind == HRS_SHADOW_I8;
+    const int Dpad = c->Dpad, KS = i8 ? Dpad / 32 : Dpad / 16;
+    const bool wide = !i8 && Dpad == 1024;
+    const int TR = i8 ? (KS <= 24 ? 64 : 32) : (Dpad <= 384 ? 64 : 32);
     const int BC = 1024;  // queries per chunk
     // workspace carve
     size_t off = 0;
@@ -612,6 +821,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_max = carve((size_t)BC * HRS_MAX_STREAMS * sizeof(float));
     const size_t o_tau = carve((size_t)BC * sizeof(float));
     const size_t o_cnt = carve((size_t)BC * sizeof(int));
+    const size_t o_qs = carve((size_t)BC * sizeof(float));
+    const size_t o_kq = carve((size_t)BC * sizeof(float));
     const size_t o_cand = carve((size_t)BC * HRS_CAND_CAP * sizeof(uint64_t));
     int rc = hrs_ws_reserve(ctx, &ctx->ws_mfma, off);
     if (rc) return rc;
@@ -627,11 +838,18 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
         const int nqg = bpad / (wide ? 128 : MF_QPB);
         const int nslices = HRS_NUM_CU / nqg;
-        hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
-                           bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn));
+        if (i8)
+            hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
+                               bpad, Dpad, (int8_t*)(ws + o_qb), (double*)(ws + o_qn), (float*)(ws + o_qs),
+                               (float*)(ws + o_kq));
+        else
+            hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
+                               bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn));
         MfmaArgs a;
-        a.shadow = c->shadow;
-        a.qb = (const __bf16*)(ws + o_qb);
+        a.shadow = (const char*)c->shadow;
+        a.qb = (const char*)(ws + o_qb);
+        a.group = nullptr;
+        a.kq = i8 ? (const float*)(ws + o_kq) : nullptr;
         a.N = c->N;
         a.tiles = tiles;
         a.row_offset = c->row_offset;
@@ -652,13 +870,13 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         if (j < 16) j = 16;
         if (j > M / 2) j = M / 2;
 
-#define HRS_SCAN(KS_, TR_)                                     \
+#define HRS_SCAN(KS_, TR_, I8_)                                \
     case KS_:                                                  \
-        rc = launch_scan<KS_, TR_>(a, true, st);               \
+        rc = launch_scan<KS_, TR_, I8_>(a, true, c, st);       \
         if (rc) return rc;                                     \
         hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt); \
         hrs_prof_begin(ctx, st);                               \
-        rc = launch_scan<KS_, TR_>(a, false, st);              \
+        rc = launch_scan<KS_, TR_, I8_>(a, false, c, st);      \
         hrs_prof_end(ctx, st);                                 \
         if (rc) return rc;                                     \
         break;
@@ -676,15 +894,28 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             hipLaunchKernelGGL(k_mfma_scan_wide<false>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
             hrs_prof_end(ctx, st);
             HRS_CHECK_HIP(hipGetLastError());
-        } else
-        switch (KS) {
-            HRS_SCAN(8, 64)
-            HRS_SCAN(16, 64)
-            HRS_SCAN(24, 64)
-            HRS_SCAN(32, 32)
-            default:
-                hrs_set_error("hrs_launch_mfma: no kernel for padded depth %d", Dpad);
-                return HRS_ERR_UNSUPPORTED;
+        } else if (i8) {
+            switch (KS) {
+                HRS_SCAN(4, 64, true)
+                HRS_SCAN(8, 64, true)
+                HRS_SCAN(12, 64, true)
+                HRS_SCAN(16, 64, true)
+                HRS_SCAN(24, 64, true)
+                HRS_SCAN(32, 32, true)
+                default:
+                    hrs_set_error("hrs_launch_mfma: no int8 kernel for padded depth %d", Dpad);
+                    return HRS_ERR_UNSUPPORTED;
+            }
+        } else {
+            switch (KS) {
+                HRS_SCAN(8, 64, false)
+                HRS_SCAN(16, 64, false)
+                HRS_SCAN(24, 64, false)
+                HRS_SCAN(32, 32, false)
+                default:
+                    hrs_set_error("hrs_launch_mfma: no kernel for padded depth %d", Dpad);
+                    return HRS_ERR_UNSUPPORTED;
+            }
         }
 #undef HRS_SCAN
         SelectArgs s;
@@ -701,6 +932,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.qn2 = (const double*)(ws + o_qn);
         s.norm_stats = c->norm_stats;
         s.eps_rel = MF_EPS_BASE + MF_EPS_PER_D * Dpad;
+        s.qscale = i8 ? (const float*)(ws + o_qs) : nullptr;
         s.keys_out = keys_out;
         s.qlist = qlist;
         s.nflag = nflag;

@@ -22,7 +22,7 @@ def _stream():
 class Corpus:
     """The embedding matrix of one shard, registered with the engine (keeps `matrix` alive)."""
 
-    def __init__(self, engine, matrix, row_offset=0):
+    def __init__(self, engine, matrix, row_offset=0, shadow="auto"):
         if not (matrix.is_cuda and matrix.dtype == torch.float32 and matrix.dim() == 2 and matrix.is_contiguous()):
             raise ValueError("corpus must be a contiguous fp32 [N, D] CUDA tensor")
         self.engine = engine
@@ -35,6 +35,12 @@ class Corpus:
             "hrs_corpus_register",
         )
         self._h = h
+        if shadow != "auto":
+            self.set_shadow(shadow)
+
+    def set_shadow(self, kind):
+        """Rebuild the scan shadow: "auto" (int8 up to depth 512, else bf16), "i8", "bf16" or "none" (exact scan only)."""
+        N.check(N.lib().hrs_corpus_shadow(self.engine._ctx, self._h, N.SHADOWS[kind], _stream()), "hrs_corpus_shadow")
 
     def norm_stats(self):
         mn, mx = C.c_double(), C.c_double()
@@ -140,8 +146,8 @@ class Engine:
             self._ctx = None
 
     # ---- registration -------------------------------------------------------------------------
-    def corpus(self, matrix, row_offset=0):
-        return Corpus(self, matrix, row_offset)
+    def corpus(self, matrix, row_offset=0, shadow="auto"):
+        return Corpus(self, matrix, row_offset, shadow)
 
     def postings(self, doc_offs, term_ids, row_offset=0):
         return Postings(self, doc_offs, term_ids, row_offset)

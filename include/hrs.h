@@ -51,6 +51,14 @@ enum hrs_space { HRS_SPACE_L2 = 0, HRS_SPACE_COSINE = 1, HRS_SPACE_IP = 2 };
  * falls back to EXACT for any query it cannot prove). */
 enum hrs_score_mode { HRS_MODE_AUTO = 0, HRS_MODE_EXACT = 1, HRS_MODE_MFMA = 2 };
 
+/* The reduced-precision copy of the corpus that the MFMA scan streams.  I8: int8 with one fp32 scale
+ * per 32-row group, half the bytes and twice the matrix-core rate of BF16.  The choice never changes
+ * results (candidates are re-scored exactly and the top-k is proven against the shadow's rigorous
+ * error bound); it only changes how many queries need the exact fallback: the int8 bound grows with
+ * the depth relative to the spread of the scores, so AUTO (what hrs_corpus_register builds) is I8 up
+ * to depth 512 and BF16 above. */
+enum hrs_shadow_kind { HRS_SHADOW_NONE = 0, HRS_SHADOW_BF16 = 1, HRS_SHADOW_I8 = 2, HRS_SHADOW_AUTO = 3 };
+
 #define HRS_PAD_KEY 0xFFFFFFFFFFFFFFFFull
 #define HRS_MAX_K 128
 
@@ -68,11 +76,15 @@ int hrs_ctx_destroy(hrs_ctx* ctx);
 /* Stands in for the server side of collection.add(...) (scripts/chromadb_helper.py:397-401,
  * 462-466, 474-478): C_dev is the fp32 [N, D] row-major embedding matrix of this shard, row i
  * being global row row_offset + i.  The corpus handle keeps C_dev (caller must keep it alive)
- * and owns a bf16 shadow copy plus row-norm statistics that it builds on `stream`.
+ * and owns a shadow copy (HRS_SHADOW_AUTO) plus row statistics that it builds on `stream`.
  * D must be a multiple of 4; N + row_offset must stay below 2^32. */
 int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, int D, int64_t row_offset, void* stream,
                         hrs_corpus** out);
 int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* corpus);
+/* Rebuilds the corpus' shadow as `kind` (hrs_shadow_kind) on `stream`; waits for the device first.
+ * No counterpart in the reference (ChromaDB's index parameters are fixed at collection creation,
+ * scripts/chromadb_helper.py:82-86); NONE leaves only the exact scan. */
+int hrs_corpus_shadow(hrs_ctx* ctx, hrs_corpus* corpus, int kind, void* stream);
 /* Waits for `stream`, then reports min/max squared row norm (0/0 for an empty corpus). */
 int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* corpus, void* stream, double* min_norm2, double* max_norm2);
 

@@ -84,9 +84,10 @@ def test_empty_corpus(eng):
     corpus.close()
 
 
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
 @pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
-def test_mfma_scan_bit_exact(eng, space):
-    """Matrix-core path: same keys as the exact oracle (ids, order and fp32 distances)."""
+def test_mfma_scan_bit_exact(eng, space, shadow):
+    """Matrix-core path (int8 and bf16 shadows): same keys as the exact oracle (ids, order and fp32 distances)."""
     rng = np.random.default_rng(11)
     n, d, b, k = 150_001, 384, 300, 20
     C = _unit(rng, n, d)
@@ -98,7 +99,7 @@ def test_mfma_scan_bit_exact(eng, space):
     C[77777] = C[0]
     C[150_000] = C[0]
     want = so.topk_keys(Q, C, k, space)
-    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
     dist, rows, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
     torch.cuda.synchronize()
     st = eng.score_stats()
@@ -109,9 +110,11 @@ def test_mfma_scan_bit_exact(eng, space):
     corpus.close()
 
 
-@pytest.mark.parametrize("d,b,space", [(1024, 200, "cosine"), (1024, 40, "l2"), (768, 130, "ip")])
-def test_mfma_scan_wide_bit_exact(eng, d, b, space):
-    """Depth (512, 1024]: the four-wave kernel with AGPR-resident query fragments, all query-group counts."""
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
+@pytest.mark.parametrize("d,b,space", [(1024, 200, "cosine"), (1024, 40, "l2"), (768, 130, "ip"), (512, 70, "l2"), (100, 300, "cosine")])
+def test_mfma_scan_wide_bit_exact(eng, d, b, space, shadow):
+    """Other depths: every k-step count of both shadows (bf16 above 512: the four-wave kernel with
+    AGPR-resident query fragments), all query-group counts."""
     rng = np.random.default_rng(d + b)
     n, k = 90_003, 10
     C = _unit(rng, n, d)
@@ -123,17 +126,22 @@ def test_mfma_scan_wide_bit_exact(eng, d, b, space):
         Q[j] /= np.linalg.norm(Q[j])
     C[n - 1] = C[0]
     want = so.topk_keys(Q, C, k, space)
-    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
     _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
     torch.cuda.synchronize()
     st = eng.score_stats()
     got = _keys(keys)
     assert np.array_equal(got, want), f"mismatching queries: {np.nonzero((got != want).any(1))[0][:10]} stats={st}"
-    assert st["fallback_queries"] <= 3 and st["overflow_queries"] == 0, st
+    # the int8 error bound is wide next to the score spread of deep random rows: those queries take the
+    # exact fallback (same results); AUTO therefore builds the bf16 shadow above depth 512
+    if not (shadow == "i8" and d > 512):
+        assert st["fallback_queries"] <= 3, st
+    assert st["overflow_queries"] == 0, st
     corpus.close()
 
 
-def test_mfma_fallback_on_heavy_ties(eng):
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
+def test_mfma_fallback_on_heavy_ties(eng, shadow):
     """More exact duplicates of the best row than the re-score window: the proof fails and the
     query is answered by the exact scan, still bit-exact."""
     rng = np.random.default_rng(12)
@@ -143,7 +151,7 @@ def test_mfma_fallback_on_heavy_ties(eng):
     Q = _unit(rng, b, d)
     Q[3] = C[5]
     want = so.topk_keys(Q, C, k, "l2")
-    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
     _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, mode="mfma", want_keys=True)
     torch.cuda.synchronize()
     st = eng.score_stats()

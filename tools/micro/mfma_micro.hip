@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 __device__ __forceinline__ void glds16(const char* sbase, int voff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
-template <int S, int NW>
+template <int S, int NW, bool I8 = false>
 __global__ __launch_bounds__(NW * 64) void kst(float* out, const char* src, int stages) {
     constexpr int KS = 24, PF = 4, STAGE = 24576, NBUF = 6, IPW = STAGE / (NW * 1024);
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -113,7 +113,15 @@ __global__ __launch_bounds__(NW * 64) void kst(float* out, const char* src, int 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + PF < KS) av[s + PF] = *(lp)(size_t)(sb + (((2 * (s + PF) + h) & 15) ^ (i & 15)) * 16 + ((s + PF) >> 3) * 256);
-            if (s == 0) {
+            if (I8) {
+                if (s == 0) {
+                    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(c0) : "v"(av[s]), "a"(q0[s]));
+                    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(c1) : "v"(av[s]), "a"(q1[s]));
+                } else {
+                    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c0) : "v"(av[s]), "a"(q0[s]));
+                    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c1) : "v"(av[s]), "a"(q1[s]));
+                }
+            } else if (s == 0) {
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c0) : "v"(av[s]), "a"(q0[s]));
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c1) : "v"(av[s]), "a"(q1[s]));
             } else {
@@ -129,21 +137,21 @@ __global__ __launch_bounds__(NW * 64) void kst(float* out, const char* src, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
-template <int S, int NW>
+template <int S, int NW, bool I8 = false>
 void runst(const char* name, float* out, const char* src) {
     const int stages = 5000, lds = 6 * 24576;
-    CHECK(hipFuncSetAttribute((const void*)kst<S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)kst<S, NW, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((kst<S, NW>), dim3(256), dim3(NW * 64), lds, 0, out, src, 50);
+    hipLaunchKernelGGL((kst<S, NW, I8>), dim3(256), dim3(NW * 64), lds, 0, out, src, 50);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((kst<S, NW>), dim3(256), dim3(NW * 64), lds, 0, out, src, stages);
+    hipLaunchKernelGGL((kst<S, NW, I8>), dim3(256), dim3(NW * 64), lds, 0, out, src, stages);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double mfma = (double)stages * 48 * NW * 256;
-    printf("%-46s waves=%d  %.3f ms  %.0f TFLOP/s\n", name, NW, ms, mfma * 32768 / (ms * 1e-3) / 1e12);
+    printf("%-46s waves=%d  %.3f ms  %.0f T(FL)OP/s\n", name, NW, ms, mfma * (I8 ? 65536 : 32768) / (ms * 1e-3) / 1e12);
 }
 
 template <int V, bool RND = false>
@@ -195,5 +203,7 @@ int main() {
     runst<0, 4>("staged: ds_read -> 2 MFMA", out, src);
     runst<1, 4>("staged + barrier", out, src);
     runst<2, 4>("staged + barrier + LDS-DMA", out, src);
+    runst<0, 4, true>("i8 staged: ds_read -> 2 MFMA", out, src);
+    runst<2, 4, true>("i8 staged + barrier + LDS-DMA", out, src);
     return 0;
 }
