@@ -675,10 +675,18 @@ struct SelectArgs {
     int qbase;           // first query of this chunk
 };
 
+#define HRS_RESCORE_MAX 1024  // the re-scored prefix grows in rounds of HRS_RESCORE up to this many
+
+// Per query: sort the candidates by their recorded score (an upper bound of the true score up to the
+// shadow's error term), re-score the best HRS_RESCORE exactly, and extend the re-scored prefix while any
+// candidate outside it could still beat the current k-th exact distance.  Accept when nothing outside
+// the prefix -- recorded or never recorded (score <= tau) -- can; otherwise queue the query for the
+// exact scan.
 template <int SPACE>
 __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     __shared__ uint64_t s[HRS_CAND_CAP];
-    __shared__ uint64_t ek[HRS_RESCORE];
+    __shared__ uint64_t ek[HRS_RESCORE_MAX];
+    __shared__ int need_s, ok;
     const int ql = blockIdx.x;       // query within the chunk
     const int q = a.qbase + ql;      // query in the caller's batch
     const int tid = threadIdx.x;
@@ -688,82 +696,104 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     int n2 = 256;
     while (n2 < c) n2 <<= 1;
     for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP + t] : HRS_PAD_KEY;
+    for (int t = tid; t < HRS_RESCORE_MAX; t += 256) ek[t] = HRS_PAD_KEY;
     bitonic_sort_u64(s, n2, tid, 256);
-    const int R = c < HRS_RESCORE ? c : HRS_RESCORE;
-    uint64_t mine = HRS_PAD_KEY;
-    if (tid < R) {
-        const uint32_t grow = (uint32_t)(s[tid] & 0xFFFFFFFFull);
-        const float* cr = a.C + (size_t)((int64_t)grow - a.row_offset) * a.D;
-        const float* qr = a.Q + (size_t)q * a.D;
-        double acc = 0.0, nc = 0.0;
-        for (int d0 = 0; d0 < a.D; d0 += 4) {
-            const float4 cv = *(const float4*)(cr + d0);
-            const float4 qv = *(const float4*)(qr + d0);
-            const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
-            const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
-            if (SPACE == HRS_SPACE_L2) {
-                const double e0 = q0 - c0, e1 = q1 - c1, e2 = q2 - c2, e3 = q3 - c3;
-                acc = fma(e0, e0, acc);
-                acc = fma(e1, e1, acc);
-                acc = fma(e2, e2, acc);
-                acc = fma(e3, e3, acc);
-            } else {
-                acc = fma(q0, c0, acc);
-                acc = fma(q1, c1, acc);
-                acc = fma(q2, c2, acc);
-                acc = fma(q3, c3, acc);
-                if (SPACE == HRS_SPACE_COSINE) {
-                    nc = fma(c0, c0, nc);
-                    nc = fma(c1, c1, nc);
-                    nc = fma(c2, c2, nc);
-                    nc = fma(c3, c3, nc);
+
+    const float* qr = a.Q + (size_t)q * a.D;
+    const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
+    const double sq = a.qscale ? (double)a.qscale[ql] : 1.0;
+    // smallest distance a row can have whose recorded score is at most A
+    auto dist_floor = [&](float A) -> double {
+        double sb;
+        if (a.qscale) {
+            // A bounds score / scale; allow for the fp32 roundings made while it was computed
+            const double v = (double)A * sq;
+            sb = v + 2e-6 * fabs(v) + 1e-6 * sqrt(qn) * sqrt(ncmax) + 1e-30;
+        } else {
+            sb = (double)A + a.eps_rel * sqrt(qn) * sqrt(ncmax) + 1e-30;
+        }
+        if (SPACE == HRS_SPACE_L2) return qn + ncmin - 2.0 * sb;
+        if (SPACE == HRS_SPACE_IP) return 1.0 - sb;
+        return qn > 0.0 ? 1.0 - sb / (sqrt(qn) * sqrt(sb > 0.0 ? ncmin : ncmax)) : 2.0;
+    };
+    double nq = 0.0;
+    if (SPACE == HRS_SPACE_COSINE) {
+        // the oracle's |q|^2 is a sequential fp64 sum: recompute it the same way
+        for (int d0 = 0; d0 < a.D; ++d0) nq = fma((double)qr[d0], (double)qr[d0], nq);
+    }
+    int done = 0;                       // candidates [0, done) are re-scored
+    int want = c < HRS_RESCORE ? c : HRS_RESCORE;
+    bool accept = false;
+    while (true) {
+        const int idx = done + tid;
+        if (idx < want) {
+            const uint32_t grow = (uint32_t)(s[idx] & 0xFFFFFFFFull);
+            const float* cr = a.C + (size_t)((int64_t)grow - a.row_offset) * a.D;
+            double acc = 0.0, nc = 0.0;
+            for (int d0 = 0; d0 < a.D; d0 += 4) {
+                const float4 cv = *(const float4*)(cr + d0);
+                const float4 qv = *(const float4*)(qr + d0);
+                const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
+                const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
+                if (SPACE == HRS_SPACE_L2) {
+                    const double e0 = q0 - c0, e1 = q1 - c1, e2 = q2 - c2, e3 = q3 - c3;
+                    acc = fma(e0, e0, acc);
+                    acc = fma(e1, e1, acc);
+                    acc = fma(e2, e2, acc);
+                    acc = fma(e3, e3, acc);
+                } else {
+                    acc = fma(q0, c0, acc);
+                    acc = fma(q1, c1, acc);
+                    acc = fma(q2, c2, acc);
+                    acc = fma(q3, c3, acc);
+                    if (SPACE == HRS_SPACE_COSINE) {
+                        nc = fma(c0, c0, nc);
+                        nc = fma(c1, c1, nc);
+                        nc = fma(c2, c2, nc);
+                        nc = fma(c3, c3, nc);
+                    }
                 }
             }
-        }
-        double d;
-        if (SPACE == HRS_SPACE_L2) {
-            d = acc;
-        } else if (SPACE == HRS_SPACE_IP) {
-            d = 1.0 - acc;
-        } else {
-            // the oracle's |q|^2 is a sequential fp64 sum: recompute it the same way
-            double nq = 0.0;
-            for (int d0 = 0; d0 < a.D; ++d0) nq = fma((double)qr[d0], (double)qr[d0], nq);
-            d = (nq == 0.0 || nc == 0.0) ? 1.0 : 1.0 - acc / (sqrt(nq) * sqrt(nc));
-        }
-        mine = pack_key((float)d, grow);
-    }
-    ek[tid] = mine;
-    bitonic_sort_u64(ek, HRS_RESCORE, tid, 256);
-    __shared__ int ok;
-    if (tid == 0) {
-        bool accept = !overflow && R >= a.k;
-        if (accept) {
-            // best approximate score of anything that was not re-scored
-            const float A = c > R ? orderable_f32(~(uint32_t)(s[R] >> 32)) : a.tau[ql];
-            const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
-            double sb;
-            if (a.qscale) {
-                // A bounds score / scale of every row that was not re-scored; allow for the fp32
-                // roundings made while it was computed
-                const double v = (double)A * (double)a.qscale[ql];
-                sb = v + 2e-6 * fabs(v) + 1e-6 * sqrt(qn) * sqrt(ncmax) + 1e-30;
-            } else {
-                sb = (double)A + a.eps_rel * sqrt(qn) * sqrt(ncmax) + 1e-30;
-            }
-            double dmin;
+            double d;
             if (SPACE == HRS_SPACE_L2)
-                dmin = qn + ncmin - 2.0 * sb;
+                d = acc;
             else if (SPACE == HRS_SPACE_IP)
-                dmin = 1.0 - sb;
+                d = 1.0 - acc;
             else
-                dmin = qn > 0.0 ? 1.0 - sb / (sqrt(qn) * sqrt(sb > 0.0 ? ncmin : ncmax)) : 2.0;
-            const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
-            accept = dk + 1e-6 * (1.0 + fabs(dmin)) < dmin;
+                d = (nq == 0.0 || nc == 0.0) ? 1.0 : 1.0 - acc / (sqrt(nq) * sqrt(nc));
+            ek[idx] = pack_key((float)d, grow);
         }
+        done = want;
+        if (tid == 0) need_s = 0;
+        bitonic_sort_u64(ek, HRS_RESCORE_MAX, tid, 256);  // (its barriers also publish need_s)
+        if (overflow || done < a.k) break;
+        const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
+        // recorded scores are sorted descending, so the candidates that could still beat dk are a prefix
+        int mine = 0;
+        for (int t = tid; t < c; t += 256) {
+            const float A = orderable_f32(~(uint32_t)(s[t] >> 32));
+            const double dmin = dist_floor(A);
+            if (!(dk + 1e-6 * (1.0 + fabs(dmin)) < dmin)) mine = t + 1;
+        }
+        if (mine) atomicMax(&need_s, mine);
+        __syncthreads();
+        const int need = need_s;
+        __syncthreads();
+        if (need <= done) {
+            // and nothing that was never recorded (score <= tau) may beat it either
+            const double dmin = dist_floor(a.tau[ql]);
+            accept = dk + 1e-6 * (1.0 + fabs(dmin)) < dmin;
+            break;
+        }
+        if (done >= HRS_RESCORE_MAX) break;
+        want = need < done + HRS_RESCORE ? need : done + HRS_RESCORE;
+        if (want > HRS_RESCORE_MAX) want = HRS_RESCORE_MAX;
+    }
+    if (tid == 0) {
         ok = accept;
         atomicMax((unsigned long long*)&a.stats[1], (unsigned long long)craw);
         if (overflow) atomicAdd((unsigned long long*)&a.stats[2], 1ull);
+        if (done > HRS_RESCORE) atomicAdd((unsigned long long*)&a.stats[3], 1ull);
         if (!accept) {
             atomicAdd((unsigned long long*)&a.stats[0], 1ull);
             const int p = atomicAdd(a.nflag, 1);

@@ -142,21 +142,24 @@ def test_mfma_scan_wide_bit_exact(eng, d, b, space, shadow):
 
 @pytest.mark.parametrize("shadow", ["i8", "bf16"])
 def test_mfma_fallback_on_heavy_ties(eng, shadow):
-    """More exact duplicates of the best row than the re-score window: the proof fails and the
-    query is answered by the exact scan, still bit-exact."""
+    """More exact duplicates of the best row than the largest re-score window: the proof fails and the
+    query is answered by the exact scan, still bit-exact.  A second query has more duplicates than the
+    first window but fewer than the largest: it is proven after the window has grown."""
     rng = np.random.default_rng(12)
     n, d, b, k = 70_000, 128, 20, 10
     C = _unit(rng, n, d)
-    C[1000:1400] = C[5]
+    C[1000:2600] = C[5]
+    C[40000:40400] = C[7]
     Q = _unit(rng, b, d)
     Q[3] = C[5]
+    Q[4] = C[7]
     want = so.topk_keys(Q, C, k, "l2")
     corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
     _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, mode="mfma", want_keys=True)
     torch.cuda.synchronize()
     st = eng.score_stats()
     assert np.array_equal(_keys(keys), want), st
-    assert st["fallback_queries"] >= 1
+    assert 1 <= st["fallback_queries"] <= 3, st
     corpus.close()
 
 
