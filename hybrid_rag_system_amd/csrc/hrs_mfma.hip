@@ -39,7 +39,7 @@ template <bool I8> struct scan_types { typedef bf16x8 frag; typedef f32x16 acc; 
 template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 #define I8_EMAX 0.5001   // bound of |x / scale - rint(x / scale)| incl. the fp32 division error
 
-#define MF_QPB 256   // queries per workgroup
+#define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
 
@@ -69,11 +69,11 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 }
 
 template <int KS, int TR, bool PRE, int QT, bool I8>
-__global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
+__global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     typedef typename scan_types<I8>::frag frag_t;
     typedef typename scan_types<I8>::acc acc_t;
     constexpr int MF_QPW = 32 * QT;           // queries per wave
-    constexpr int NW = 8 / QT;                // waves per workgroup (256 queries)
+    constexpr int NW = 8;                     // waves per workgroup (256 * QT queries)
     constexpr int RB = KS * 32;               // row bytes
     constexpr int TILE_BYTES = TR * RB;
     constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512 / QT) void k_mfma_scan(MfmaArgs a) {
     const int qg = loc % a.nqg;
     const int nslices = HRS_NUM_CU / a.nqg;
     const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
-    const int q0 = qg * MF_QPB + wv * MF_QPW;
+    const int q0 = qg * (MF_QPB * QT) + wv * MF_QPW;
 
     frag_t qf[QT][KS];
 #pragma unroll
@@ -805,26 +805,36 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         for (int t = tid; t < a.k; t += 256) a.keys_out[(size_t)q * a.k + t] = ek[t];
 }
 
-template <int KS, int TR, bool I8>
-static int launch_scan(MfmaArgs a, bool pre, const hrs_corpus* c, hipStream_t st) {
+template <int KS, int TR, bool I8, int QT>
+static int launch_scan_qt(const MfmaArgs& a, bool pre, hipStream_t st) {
     const size_t lds = (size_t)3 * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, 1, I8>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, QT, I8>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false, 1, I8>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false, QT, I8>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    a.group = pre ? c->group_pre : c->group_main;
     if (pre)
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true, 1, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     else
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false, 1, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
 
+// Two 32-query tiles per wave (each corpus fragment read from LDS feeds two MFMAs) where the query
+// fragments of 64 queries fit the wave's registers: the int8 shadow up to 12 k-steps (depth 384).
+template <int KS, bool I8>
+constexpr int scan_qt_max() { return (I8 && KS <= 12) ? 2 : 1; }
+
+template <int KS, int TR, bool I8>
+static int launch_scan(MfmaArgs a, bool pre, int qt, const hrs_corpus* c, hipStream_t st) {
+    a.group = pre ? c->group_pre : c->group_main;
+    if (qt == 2 && scan_qt_max<KS, I8>() == 2) return launch_scan_qt<KS, TR, I8, scan_qt_max<KS, I8>()>(a, pre, st);
+    return launch_scan_qt<KS, TR, I8, 1>(a, pre, st);
+}
 
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
                     hipStream_t st) {
@@ -866,7 +876,9 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     for (int qbase = 0; qbase < B; qbase += BC) {
         const int bc = B - qbase < BC ? B - qbase : BC;
         const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
-        const int nqg = bpad / (wide ? 128 : MF_QPB);
+        // 64 queries per wave for large batches on the shallow int8 kernels
+        const int qt = (i8 && KS <= 12 && bpad >= 512 && !getenv("HRS_SCAN_QT1")) ? 2 : 1;
+        const int nqg = bpad / (wide ? 128 : MF_QPB * qt);
         const int nslices = HRS_NUM_CU / nqg;
         if (i8)
             hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
@@ -902,11 +914,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
 
 #define HRS_SCAN(KS_, TR_, I8_)                                \
     case KS_:                                                  \
-        rc = launch_scan<KS_, TR_, I8_>(a, true, c, st);       \
+        rc = launch_scan<KS_, TR_, I8_>(a, true, qt, c, st);   \
         if (rc) return rc;                                     \
         hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt); \
         hrs_prof_begin(ctx, st);                               \
-        rc = launch_scan<KS_, TR_, I8_>(a, false, c, st);      \
+        rc = launch_scan<KS_, TR_, I8_>(a, false, qt, c, st);  \
         hrs_prof_end(ctx, st);                                 \
         if (rc) return rc;                                     \
         break;
