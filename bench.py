@@ -112,7 +112,7 @@ def bench_embed(eng, batches=4, B=1024, S=256):
     dt = (time.perf_counter() - t0) / batches
     enc.close()
     flops = 6.040e9 * B  # 23 592 960 flop per token x 256 tokens
-    return {"chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "tflops": flops / dt / 1e12, "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS,
+    return {"chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "tflops": flops / dt / 1e12, "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS["bf16"],
             "config": f"MiniLM-L6 geometry, generated weights, batch {B} x {S} tokens, bf16 MFMA"}
 
 

@@ -92,18 +92,30 @@ __device__ __forceinline__ uint64_t pack_key(float d32, uint32_t row) {
 }
 
 // Bitonic sort of n (power of two) uint64 keys in LDS, ascending; all threads of the block call it.
+// Every thread owns compare-exchange PAIRS (pair p of a pass with stride j joins i = p with a zero bit
+// inserted at j, and i + j), four at a time so that their LDS reads are in flight together.
 __device__ __forceinline__ void bitonic_sort_u64(uint64_t* s, int n, int tid, int nthreads) {
+    const int half = n >> 1;
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             __syncthreads();
-            for (int i = tid; i < n; i += nthreads) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    uint64_t a = s[i], b = s[ixj];
-                    bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        s[i] = b;
-                        s[ixj] = a;
+            for (int p0 = tid; p0 < half; p0 += 4 * nthreads) {
+                uint64_t a[4], b[4];
+                int ii[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u * nthreads;
+                    ii[u] = p < half ? (((p & ~(j - 1)) << 1) | (p & (j - 1))) : -1;
+                    if (ii[u] >= 0) {
+                        a[u] = s[ii[u]];
+                        b[u] = s[ii[u] + j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ii[u] >= 0 && (a[u] > b[u]) == ((ii[u] & k) == 0)) {
+                        s[ii[u]] = b[u];
+                        s[ii[u] + j] = a[u];
                     }
                 }
             }

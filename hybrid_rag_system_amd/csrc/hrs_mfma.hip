@@ -686,6 +686,7 @@ template <int SPACE>
 __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     __shared__ uint64_t s[HRS_CAND_CAP];
     __shared__ uint64_t ek[HRS_RESCORE_MAX];
+    __shared__ __attribute__((aligned(16))) float qs[1024];  // the query (D <= 1024 on this path)
     __shared__ int need_s, ok;
     const int ql = blockIdx.x;       // query within the chunk
     const int q = a.qbase + ql;      // query in the caller's batch
@@ -697,9 +698,10 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     while (n2 < c) n2 <<= 1;
     for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP + t] : HRS_PAD_KEY;
     for (int t = tid; t < HRS_RESCORE_MAX; t += 256) ek[t] = HRS_PAD_KEY;
+    const float* qr = a.Q + (size_t)q * a.D;
+    for (int t = tid; t < a.D; t += 256) qs[t] = qr[t];
     bitonic_sort_u64(s, n2, tid, 256);
 
-    const float* qr = a.Q + (size_t)q * a.D;
     const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
     const double sq = a.qscale ? (double)a.qscale[ql] : 1.0;
     // smallest distance a row can have whose recorded score is at most A
@@ -730,9 +732,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
             const uint32_t grow = (uint32_t)(s[idx] & 0xFFFFFFFFull);
             const float* cr = a.C + (size_t)((int64_t)grow - a.row_offset) * a.D;
             double acc = 0.0, nc = 0.0;
-            for (int d0 = 0; d0 < a.D; d0 += 4) {
-                const float4 cv = *(const float4*)(cr + d0);
-                const float4 qv = *(const float4*)(qr + d0);
+            auto step4 = [&](const float4 cv, const float4 qv) __attribute__((always_inline)) {
                 const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
                 const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
                 if (SPACE == HRS_SPACE_L2) {
@@ -753,7 +753,18 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
                         nc = fma(c3, c3, nc);
                     }
                 }
+            };
+            // a thread walks its own row: take a whole 128-byte line per step (8 loads in flight) so
+            // that every line is fetched once; the query comes from LDS
+            int d0 = 0;
+            for (; d0 + 32 <= a.D; d0 += 32) {
+                float4 cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cv[u] = *(const float4*)(cr + d0 + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) step4(cv[u], *(const float4*)(qs + d0 + 4 * u));
             }
+            for (; d0 < a.D; d0 += 4) step4(*(const float4*)(cr + d0), *(const float4*)(qs + d0));
             double d;
             if (SPACE == HRS_SPACE_L2)
                 d = acc;
@@ -765,7 +776,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         }
         done = want;
         if (tid == 0) need_s = 0;
-        bitonic_sort_u64(ek, HRS_RESCORE_MAX, tid, 256);  // (its barriers also publish need_s)
+        bitonic_sort_u64(ek, done <= 256 ? 256 : (done <= 512 ? 512 : HRS_RESCORE_MAX), tid, 256);  // (its barriers also publish need_s)
         if (overflow || done < a.k) break;
         const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
         // recorded scores are sorted descending, so the candidates that could still beat dk are a prefix
