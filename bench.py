@@ -2,14 +2,19 @@
 """Headline benchmark: hybrid top-10 queries/sec over a 10M x 384 corpus (BASELINE.json config 4).
 
 One step = one pass of the hot path over one batch of 1024 queries whose embeddings are already in
-HBM: exact top-20 by squared-L2 distance (bf16 MFMA scan + exact fp64 re-score), keyword presence
+HBM: exact top-20 by squared-L2 distance (int8 MFMA scan + exact fp64 re-score), keyword presence
 counts of those 20 rows over forward-CSR postings, fused score 0.7*sem + 0.3*kw, stable order, top-10.
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 the 10M rows are sharded over the ranks (strong scaling: total work fixed) and every batch
-ends with one all-gather of the per-shard candidates (RCCL) and a merge.  Rank 0 prints ONE JSON line.
+With N > 1 there are two layouts.  `replica` (what `auto` picks when the whole corpus with its shadow
+and postings fits one GPU's HBM several times over, as 10M x 384 does: 23 GB of 288 GB): every rank
+holds the corpus and answers its own batch of 1024 queries -- queries are independent units, no
+data-path collective, weak scaling (per-GPU work fixed).  `shard` (corpora beyond one GPU, BASELINE
+config 5; forced with --layout shard): the rows are sharded over the ranks, every rank scores the same
+batch against its shard and every batch ends with one all-gather of the per-shard candidates (RCCL)
+and a merge -- strong scaling (total work fixed).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -38,12 +43,13 @@ def zipf_cdf(V, device):
     return (cdf / cdf[-1]).float().to(device)
 
 
-def make_queries(eng, B, D, n_total):
-    """Unit queries; every 10th is a corpus row plus N(0, 0.05^2/D)-scaled noise, so max(0, 1-d) > 0."""
-    q = eng.synth_rows(SEED_QUERY, 0, B, D)
-    rng = np.random.default_rng(SEED_QUERY)
+def make_queries(eng, B, D, n_total, stream=0):
+    """Unit queries; every 10th is a corpus row plus N(0, 0.05^2/D)-scaled noise, so max(0, 1-d) > 0.
+    `stream` selects an independent batch (one per rank in the replica layout)."""
+    q = eng.synth_rows(SEED_QUERY + 1000 * stream, 0, B, D)
+    rng = np.random.default_rng(SEED_QUERY + 1000 * stream)
     planted = rng.integers(0, n_total, B // 10)
-    noise = eng.synth_rows(SEED_QUERY + 1, 0, B // 10, D, normalize=False)
+    noise = eng.synth_rows(SEED_QUERY + 1000 * stream + 1, 0, B // 10, D, normalize=False)
     for j, r in enumerate(planted.tolist()):
         row = eng.synth_rows(SEED_CORPUS, r, 1, D)  # any rank can regenerate any global row
         v = row[0] + 0.05 * noise[j]
@@ -147,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
+    ap.add_argument("--layout", default="auto", choices=["auto", "replica", "shard"], help="multi-GPU layout (auto: replica when the corpus fits one GPU with room to spare)")
     ap.add_argument("--shadow", default="auto", choices=["auto", "i8", "bf16"], help="scan shadow of the corpus (auto: int8 up to depth 512)")
     ap.add_argument("--no-extras", action="store_true", help="skip the embed / small-batch scan side measurements")
     args = ap.parse_args()
@@ -156,16 +163,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # rehearsal on a one-GPU box: every rank on device 0, gloo instead of RCCL (which refuses two ranks on
+    # one device); never the measured configuration
+    rehearsal = os.environ.get("HRS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     eng = Engine(local_rank)
 
     n_total, D, B, n_keep = args.rows, args.dim, args.batch, args.n_results
-    lo, hi = shard_bounds(n_total, world, rank)
+    footprint = n_total * (D * 4 + D * 2 + TERMS_PER_DOC * 4 + 8)  # fp32 rows + largest shadow + postings
+    layout = args.layout if args.layout != "auto" else ("replica" if footprint <= 96e9 else "shard")
+    if world == 1:
+        layout = "single"
+    lo, hi = shard_bounds(n_total, world, rank) if layout == "shard" else (0, n_total)
     n_local = hi - lo
     matrix = torch.empty((n_local, D), dtype=torch.float32, device=dev)
     step_rows = 1 << 20
@@ -178,11 +197,11 @@ def main():
     terms = eng.synth_postings(SEED_POST, lo, n_local, cdf, TERMS_PER_DOC)
     doc_offs = torch.arange(n_local + 1, dtype=torch.int64, device=dev) * TERMS_PER_DOC
     postings = eng.postings(doc_offs, terms.reshape(-1), row_offset=lo)
-    queries = make_queries(eng, B, D, n_total)
+    queries = make_queries(eng, B, D, n_total, stream=rank if layout == "replica" else 0)
     q_terms, q_offs = make_query_terms(B, dev)
     torch.cuda.synchronize()
 
-    searcher = ShardedHybrid(eng, corpus, postings)
+    searcher = ShardedHybrid(eng, corpus, postings, group=False if layout != "shard" else None)
 
     def step():
         return searcher.step(queries, q_terms, q_offs, n_keep, mode=args.mode)
@@ -208,13 +227,13 @@ def main():
     kern_ms, launches = eng.profile_read()
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        qps = B * args.steps / elapsed
+        qps = B * args.steps / elapsed * (world if layout == "replica" else 1)
         used_mfma = args.mode == "mfma" or (args.mode == "auto" and B > 4 and n_local >= 65536)
         kern_avg_ms = kern_ms / max(launches, 1)
         if used_mfma:
@@ -228,7 +247,7 @@ def main():
             achieved = nbytes / (kern_avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_exact_scan", "kernel_ms": kern_avg_ms}
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and (n_local, D, B) == (10_000_000, 384, 1024):  # measured for this shape only
             try:
                 with open(traffic_file) as f:
                     roof["traffic"] = json.load(f).get(roof["kernel"])
@@ -243,7 +262,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if layout == "shard" else "weak",
             "vs_baseline": None,
             "dtype": f"{shadow} MFMA scan + fp64 exact re-score" if used_mfma else "f64",
             "data": "synthetic",
@@ -254,7 +273,8 @@ def main():
                 "dim": D,
                 "batch": B,
                 "n_results": n_keep,
-                "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                "parallelism": {"single": "single GPU", "shard": f"row-shard x{world}, one all-gather per batch", "replica": f"query-parallel x{world}: corpus replicated, {B} queries per GPU per step, no data-path collective"}[layout],
+                "global_batch": B * (world if layout == "replica" else 1),
                 "mode": args.mode,
                 "shadow": shadow,
             },

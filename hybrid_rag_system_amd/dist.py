@@ -33,7 +33,9 @@ def allgather_candidates(keys, counts, group=None):
 
 
 class ShardedHybrid:
-    """Hybrid top-n over a row-sharded corpus; every rank returns the same merged result."""
+    """Hybrid top-n over a row-sharded corpus; every rank returns the same merged result.
+    group=False: this rank holds the whole corpus (single GPU, or one replica of several) and no
+    exchange takes place even when a process group exists."""
 
     def __init__(self, engine, corpus, postings, group=None):
         self.engine, self.corpus, self.postings, self.group = engine, corpus, postings, group
@@ -44,7 +46,7 @@ class ShardedHybrid:
         # local top-2n of this shard is a superset of the shard's members of the global top-2n
         _, rows, keys = e.score_topk(self.corpus, queries, c, space=space, mode=mode, want_keys=True)
         counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self.group is not False and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             gk, gc = allgather_candidates(keys, counts, self.group)
             keys, counts = e.merge_topk(gk, gc)
         cand_dist, cand_rows = e.unpack_keys(keys)
