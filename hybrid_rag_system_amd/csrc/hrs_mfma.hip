@@ -39,6 +39,12 @@ template <bool I8> struct scan_types { typedef bf16x8 frag; typedef f32x16 acc; 
 template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 #define I8_EMAX 0.5001   // bound of |x / scale - rint(x / scale)| incl. the fp32 division error
 
+#ifndef HRS_SCAN_PF
+#define HRS_SCAN_PF 4
+#endif
+#ifndef HRS_SCAN_NBUF
+#define HRS_SCAN_NBUF 3
+#endif
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     if (count > 0) {
         typedef const __attribute__((address_space(3))) char* lds_cptr;
         typedef const __attribute__((address_space(3))) frag_t* lds_frag;
-        constexpr int PF = 4;  // A fragments in flight
+        constexpr int PF = HRS_SCAN_PF < KS ? HRS_SCAN_PF : KS;  // A fragments in flight
         // int8: the group terms of a tile come by scalar load (its counter is lgkmcnt, so the LDS-DMA
         // ring is left alone), requested one tile ahead
         float2 sc[NSUB], scn[NSUB];
@@ -176,10 +182,9 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
             }
         };
         if (I8) scale_load(tile_at(0));
-        issue(0, 0);
-        issue(1, 1);
-        issue(2, 2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+#pragma unroll
+        for (int g = 0; g < HRS_SCAN_NBUF; ++g) issue(g, g);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 1) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0;
         lds_cptr tb[NB];
@@ -233,10 +238,10 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
                 } else if (n + 1 < count) {
                     // tile boundary: tile n+1 has landed once at most one younger tile is outstanding
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 2) * IPW) : "memory");
                     __builtin_amdgcn_s_barrier();
-                    issue(n + 3, buf);  // tile n's buffer is free: every wave has consumed its fragments
-                    buf = buf + 1 == 3 ? 0 : buf + 1;
+                    issue(n + HRS_SCAN_NBUF, buf);  // tile n's buffer is free: every wave has consumed its fragments
+                    buf = buf + 1 == HRS_SCAN_NBUF ? 0 : buf + 1;
 #pragma unroll
                     for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
 #pragma unroll
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
 
 template <int KS, int TR, bool I8, int QT>
 static int launch_scan_qt(const MfmaArgs& a, bool pre, hipStream_t st) {
-    const size_t lds = (size_t)3 * TR * KS * 32;
+    const size_t lds = (size_t)HRS_SCAN_NBUF * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, QT, I8>,

@@ -141,6 +141,38 @@ def test_mfma_scan_wide_bit_exact(eng, d, b, space, shadow):
 
 
 @pytest.mark.parametrize("shadow", ["i8", "bf16"])
+@pytest.mark.parametrize("space", ["l2", "ip", "cosine"])
+def test_mfma_awkward_rows(eng, space, shadow):
+    """Rows the shadows quantise badly or not at all: zero rows and a zero group, a zero query, outliers
+    that coarsen their group's int8 scale, all-negative scores, a ragged last tile.  Results stay exact
+    (the exact fallback may answer some of these queries)."""
+    rng = np.random.default_rng(99)
+    n, d, b, k = 20_011, 192, 12, 10
+    C = _unit(rng, n, d)
+    C[64:96] = 0.0                       # a whole 32-row group of zeros
+    C[500] = 0.0                         # a single zero row
+    C[1000] *= 300.0                     # outliers: one huge row, one huge element
+    C[2000, 7] = 40.0
+    C[3000:3200] = np.abs(C[3000:3200])  # rows in the positive orthant
+    C[n - 1] = C[5]                      # duplicate in the ragged last tile
+    Q = _unit(rng, b, d)
+    Q[0] = 0.0                           # zero query
+    Q[1] = -np.abs(Q[1])                 # negative scores against the positive-orthant rows
+    Q[2] = C[1000] / np.linalg.norm(C[1000])
+    Q[3] = C[5]
+    Q[4] *= 1e-3                         # tiny and huge query norms
+    Q[5] *= 1e3
+    want = so.topk_keys(Q, C, k, space)
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    got = _keys(keys)
+    assert np.array_equal(got, want), f"mismatching queries: {np.nonzero((got != want).any(1))[0][:10]} stats={st}"
+    corpus.close()
+
+
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
 def test_mfma_fallback_on_heavy_ties(eng, shadow):
     """More exact duplicates of the best row than the largest re-score window: the proof fails and the
     query is answered by the exact scan, still bit-exact.  A second query has more duplicates than the
