@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define G_BK 64
 #define G_STAGE_BYTES ((G_BM + G_BN) * G_BK * 2)  // 57344
 
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_PLAIN = 3 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_PLAIN = 3, EPI_LN = 4 };
 
 struct GemmArgs {
     const __bf16* A;     // [M, K]
@@ -259,7 +259,14 @@ struct GemmWsArgs {
     __bf16* vf;
     int M, N, S;
     float qscale;
+    // EPI_LN (N = 384): C = LayerNorm(A W^T + bias + resid) * ln_g + ln_b
+    const __bf16* resid;  // [M, 384]
+    const float* ln_g;
+    const float* ln_b;
+    float eps;
 };
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int EPI, bool VW>
 __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
@@ -282,6 +289,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     // this workgroup's 384 biases live in LDS behind the tile ring (read back in the epilogue)
     float* bias_lds = (float*)(smem + 3 * TILE_BYTES);
     if (threadIdx.x < 384) bias_lds[threadIdx.x] = a.bias[fg * 384 + threadIdx.x];
+    if (EPI == EPI_LN && threadIdx.x < 384) {
+        bias_lds[384 + threadIdx.x] = a.ln_g[threadIdx.x];
+        bias_lds[768 + threadIdx.x] = a.ln_b[threadIdx.x];
+    }
+    float2* part = (float2*)(bias_lds + 1152);  // EPI_LN: [2][12 waves][32 tokens] (sum, sum of squares)
+    int pb = 0;
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s]));
@@ -316,15 +329,27 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     int buf = 0;
     for (int n = 0; n < count; ++n) {
         // outstanding, oldest first: DMA(n), DMA(n+1), then the NST stores of tile n-1 (none before the first tile)
+        // (EPI_LN: two subtiles of 4 stores and DMA(n+1) between them: its DMA is issued in the middle of the tile)
         if (n == 0)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
         __builtin_amdgcn_s_barrier();
-        {
-            int nb = buf + 2;
-            if (nb >= 3) nb -= 3;
-            issue(n + 2, nb);
+        int nb = buf + 2;
+        if (nb >= 3) nb -= 3;
+        if (EPI != EPI_LN) issue(n + 2, nb);
+        // EPI_LN: the residual rows come by asm loads so that their waits can be counted by hand next to
+        // the DMA's (a load the compiler knows about would be waited for with everything older, DMA included)
+        u32x2 rr[4];
+        int roff[4];
+        const char* rbase = nullptr;
+        if (EPI == EPI_LN) {
+            rbase = uniform_ptr((const char*)a.resid + (size_t)(t_begin + n) * TILE_BYTES);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                roff[g] = (i * 384 + wv * 32 + 8 * g + 4 * h) * 2;
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rr[g]) : "v"(roff[g]), "s"(rbase) : "memory");
+            }
         }
         lds_cptr tb[8];
 #pragma unroll
@@ -375,6 +400,62 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[4 * g + e] + bias_lds[wv * 32 + i]);
                     *(bf16x4*)(vb + (g >> 1) * 512 + (g & 1) * 4) = o;
+                }
+            } else if (EPI == EPI_LN) {
+                const int token = tok0 + i;
+                float v[16];
+                // residual of this subtile has landed; younger: nothing (subtile 0) or the DMA issued below (subtile 1)
+                if (sb == 0)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]) : "n"(IPW) : "memory");
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
+                    v[4 * g + 0] = acc[4 * g + 0] + bv.x + __uint_as_float(rr[g].x << 16);
+                    v[4 * g + 1] = acc[4 * g + 1] + bv.y + __uint_as_float(rr[g].x & 0xffff0000u);
+                    v[4 * g + 2] = acc[4 * g + 2] + bv.z + __uint_as_float(rr[g].y << 16);
+                    v[4 * g + 3] = acc[4 * g + 3] + bv.w + __uint_as_float(rr[g].y & 0xffff0000u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 += v[4 * g + e];
+                        s2 = fmaf(v[4 * g + e], v[4 * g + e], s2);
+                    }
+                }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (h == 0) part[(pb * 12 + wv) * 32 + i] = make_float2(s1, s2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 12; ++w) {
+                    const float2 pv = part[(pb * 12 + w) * 32 + i];
+                    t1 += pv.x;
+                    t2 += pv.y;
+                }
+                pb ^= 1;
+                const float mean = t1 * (1.0f / 384.0f);
+                const float rstd = rsqrtf(fmaxf(t2 * (1.0f / 384.0f) - mean * mean, 0.f) + a.eps);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = wv * 32 + 8 * g + 4 * h;
+                    const float4 gv = *(const float4*)(bias_lds + 384 + f);
+                    const float4 be = *(const float4*)(bias_lds + 768 + f);
+                    bf16x4 o;
+                    o[0] = (__bf16)((v[4 * g + 0] - mean) * rstd * gv.x + be.x);
+                    o[1] = (__bf16)((v[4 * g + 1] - mean) * rstd * gv.y + be.y);
+                    o[2] = (__bf16)((v[4 * g + 2] - mean) * rstd * gv.z + be.z);
+                    o[3] = (__bf16)((v[4 * g + 3] - mean) * rstd * gv.w + be.w);
+                    *(bf16x4*)(a.C + (size_t)token * 384 + f) = o;
+                }
+                if (sb == 0) {
+                    // residual of the second subtile, then the tile two ahead (its buffer was freed by the barrier at the top)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rr[g]) : "v"(roff[g] + 32 * RB), "s"(rbase) : "memory");
+                    issue(n + 2, nb);
                 }
             } else {
                 const int token = tok0 + i;
@@ -932,7 +1013,7 @@ static int launch_gemm(hrs_ctx* ctx, const GemmArgs& g, hipStream_t st) {
 template <int EPI>
 static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
     static bool attr_set = false;
-    const int lds = 3 * 64 * 768 + 384 * 4;
+    const int lds = 3 * 64 * 768 + 384 * 4 + (EPI == EPI_LN ? 2 * 384 * 4 + 2 * 12 * 32 * 8 : 0);
     if (!attr_set) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_ws<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -1037,10 +1118,13 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         gw.A = cx;
         gw.W = L.wo;
         gw.bias = L.bo;
-        gw.C = pre;
+        gw.C = y;
         gw.N = H;
-        if ((rc = launch_gemm_ws<EPI_PLAIN>(ctx, gw, st))) return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, x, L.ln1g, L.ln1b, M, e->cfg.eps, y);
+        gw.resid = x;
+        gw.ln_g = L.ln1g;
+        gw.ln_b = L.ln1b;
+        gw.eps = e->cfg.eps;
+        if ((rc = launch_gemm_ws<EPI_LN>(ctx, gw, st))) return rc;  // attention output projection + residual + LayerNorm
         gw.A = y;
         gw.W = L.wi;
         gw.bias = L.bi;
