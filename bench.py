@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hybrid_rag_system_amd.dist import ShardedHybrid, shard_bounds  # noqa: E402
+from hybrid_rag_system_amd.dist import HybridPipeline, shard_bounds  # noqa: E402
 from hybrid_rag_system_amd.engine import Engine  # noqa: E402
 
 SEED_CORPUS, SEED_QUERY, SEED_TERMS, SEED_POST = 1235, 4321, 777, 99
@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
+    ap.add_argument("--streams", type=int, default=2, help="consecutive batches alternate over this many HIP streams (1: strictly back to back)")
     ap.add_argument("--layout", default="auto", choices=["auto", "replica", "shard"], help="multi-GPU layout (auto: replica when the corpus fits one GPU with room to spare)")
     ap.add_argument("--shadow", default="auto", choices=["auto", "i8", "bf16"], help="scan shadow of the corpus (auto: int8 up to depth 512)")
     ap.add_argument("--no-extras", action="store_true", help="skip the embed / small-batch scan side measurements")
@@ -201,13 +202,21 @@ def main():
     q_terms, q_offs = make_query_terms(B, dev)
     torch.cuda.synchronize()
 
-    searcher = ShardedHybrid(eng, corpus, postings, group=False if layout != "shard" else None)
+    # batch i runs on stream i % streams (one engine = one set of workspaces per stream); the dominant
+    # kernel is timed on the first engine's launches
+    engines = [eng] + [Engine(local_rank) for _ in range(max(args.streams, 1) - 1)]
+    searcher = HybridPipeline(engines, corpus, postings, group=False if layout != "shard" else None)
 
     def step():
-        return searcher.step(queries, q_terms, q_offs, n_keep, mode=args.mode)
+        return searcher.submit(queries, q_terms, q_offs, n_keep, mode=args.mode)
+
+    for _ in range(len(engines)):  # every engine sizes its workspaces before the warmup proper
+        out = step()
+    searcher.drain()
 
     for _ in range(args.warmup):
         out = step()
+    searcher.drain()
     torch.cuda.synchronize()
     stats = eng.score_stats()
 
@@ -221,6 +230,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    searcher.drain()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -277,6 +287,7 @@ def main():
                 "global_batch": B * (world if layout == "replica" else 1),
                 "mode": args.mode,
                 "shadow": shadow,
+                "streams": len(engines),
             },
             "roofline": roof,
             "fallback_queries_per_batch": stats["fallback_queries"],

@@ -52,3 +52,31 @@ class ShardedHybrid:
         cand_dist, cand_rows = e.unpack_keys(keys)
         combined, perm = e.fuse_sort(cand_dist, counts, q_term_offs, n, boost)
         return {"cand_dist": cand_dist, "cand_rows": cand_rows, "cand_counts": counts, "combined": combined, "perm": perm}
+
+
+class HybridPipeline:
+    """Consecutive query batches on alternating HIP streams, one hrs_ctx (own workspaces) per stream.
+
+    A batch is a chain of kernels with very different appetites: the matrix-core scan fills the MFMA
+    pipes, the candidate sort / gather / exact re-score that follows is bound by the latency of
+    scattered row reads.  Run back to back on one stream they leave each other's resource idle; on two
+    streams the tail of batch i overlaps the scan of batch i + 1 (both fit a CU's LDS and registers
+    together).  Each batch still runs every kernel of ShardedHybrid.step and results are identical;
+    `submit` returns that step's tensors, valid once `drain()` (or the stream) has been waited for.
+    """
+
+    def __init__(self, engines, corpus, postings, group=None):
+        self.lanes = [(ShardedHybrid(e, corpus, postings, group), torch.cuda.Stream(device=e.device)) for e in engines]
+        self.n = 0
+
+    def submit(self, queries, q_terms, q_term_offs, n, **kw):
+        searcher, stream = self.lanes[self.n % len(self.lanes)]
+        self.n += 1
+        stream.wait_stream(torch.cuda.current_stream())  # the inputs were produced on the caller's stream
+        with torch.cuda.stream(stream):
+            out = searcher.step(queries, q_terms, q_term_offs, n, **kw)
+        return out
+
+    def drain(self):
+        for _, stream in self.lanes:
+            torch.cuda.current_stream().wait_stream(stream)
