@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     __shared__ uint64_t s[HRS_CAND_CAP];
     __shared__ uint64_t ek[HRS_RESCORE_MAX];
     __shared__ __attribute__((aligned(16))) float qs[1024];  // the query (D <= 1024 on this path)
+    __shared__ __attribute__((aligned(16))) char stage[4 * 64 * 144];  // per wave: 64 rows x one 128-byte line (+16 pad)
     __shared__ int need_s, ok;
     const int ql = blockIdx.x;       // query within the chunk
     const int q = a.qbase + ql;      // query in the caller's batch
@@ -732,10 +733,29 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     int want = c < HRS_RESCORE ? c : HRS_RESCORE;
     bool accept = false;
     while (true) {
-        const int idx = done + tid;
-        if (idx < want) {
-            const uint32_t grow = (uint32_t)(s[idx] & 0xFFFFFFFFull);
-            const float* cr = a.C + (size_t)((int64_t)grow - a.row_offset) * a.D;
+        // Re-score candidates [done, want): thread t owns candidate done + t (one fp64 chain per row, the
+        // oracle's operation order).  The rows are fetched by the wave together -- eight lanes per row, a
+        // 128-byte line per row and instruction -- into a per-wave LDS block and read back row-wise
+        // (row stride 144 bytes: conflict-free), so every cache line is requested once, whole.
+        {
+            const int lane = tid & 63;
+            const int idx = done + tid;
+            const bool live = idx < want;
+            const uint32_t grow = live ? (uint32_t)(s[idx] & 0xFFFFFFFFull) : 0u;
+            // (a thread without a candidate still helps to fetch: it points at the first row)
+            const float* cr = live ? a.C + (size_t)((int64_t)grow - a.row_offset) * a.D : a.C;
+            // pointer of the row that this lane helps to fetch in instruction j: row (8j + lane/8) of the wave
+            const char* fp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int src = 8 * j + (lane >> 3);
+                const uint64_t v = (uint64_t)cr;
+                const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+                fp[j] = (const char*)(((uint64_t)hi << 32) | lo) + (lane & 7) * 16;
+            }
+            char* wl = stage + (tid >> 6) * (64 * 144);
+            char* wr_base = wl + (lane >> 3) * 144 + (lane & 7) * 16;
+            const char* rd_base = wl + lane * 144;
             double acc = 0.0, nc = 0.0;
             auto step4 = [&](const float4 cv, const float4 qv) __attribute__((always_inline)) {
                 const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
@@ -759,25 +779,37 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
                     }
                 }
             };
-            // a thread walks its own row: take a whole 128-byte line per step (8 loads in flight) so
-            // that every line is fetched once; the query comes from LDS
-            int d0 = 0;
-            for (; d0 + 32 <= a.D; d0 += 32) {
-                float4 cv[8];
+            const int nchunk = (a.D + 31) >> 5;
+            float4 nxt[8];
+            auto fetch = [&](int c) __attribute__((always_inline)) {
+                const bool on = c * 32 + (lane & 7) * 4 < a.D;  // this lane's 16-byte piece exists in the chunk
 #pragma unroll
-                for (int u = 0; u < 8; ++u) cv[u] = *(const float4*)(cr + d0 + 4 * u);
+                for (int j = 0; j < 8; ++j) nxt[j] = on ? *(const float4*)(fp[j] + c * 128) : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            fetch(0);
+            for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) step4(cv[u], *(const float4*)(qs + d0 + 4 * u));
+                for (int j = 0; j < 8; ++j) *(float4*)(wr_base + j * (8 * 144)) = nxt[j];
+                if (c + 1 < nchunk) fetch(c + 1);  // in flight under this chunk's arithmetic
+                // only this wave touches its block: LDS operations of a wave complete in order
+                const int np = min(8, (a.D - c * 32) >> 2);
+                if (np == 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) step4(*(const float4*)(rd_base + u * 16), *(const float4*)(qs + c * 32 + 4 * u));
+                } else {
+                    for (int u = 0; u < np; ++u) step4(*(const float4*)(rd_base + u * 16), *(const float4*)(qs + c * 32 + 4 * u));
+                }
             }
-            for (; d0 < a.D; d0 += 4) step4(*(const float4*)(cr + d0), *(const float4*)(qs + d0));
-            double d;
-            if (SPACE == HRS_SPACE_L2)
-                d = acc;
-            else if (SPACE == HRS_SPACE_IP)
-                d = 1.0 - acc;
-            else
-                d = (nq == 0.0 || nc == 0.0) ? 1.0 : 1.0 - acc / (sqrt(nq) * sqrt(nc));
-            ek[idx] = pack_key((float)d, grow);
+            if (live) {
+                double d;
+                if (SPACE == HRS_SPACE_L2)
+                    d = acc;
+                else if (SPACE == HRS_SPACE_IP)
+                    d = 1.0 - acc;
+                else
+                    d = (nq == 0.0 || nc == 0.0) ? 1.0 : 1.0 - acc / (sqrt(nq) * sqrt(nc));
+                ek[idx] = pack_key((float)d, grow);
+            }
         }
         done = want;
         if (tid == 0) need_s = 0;
