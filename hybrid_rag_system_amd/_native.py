@@ -20,6 +20,7 @@ EXPORTS = [
     "hrs_last_error",
     "hrs_ctx_create",
     "hrs_ctx_destroy",
+    "hrs_ctx_set_peer",
     "hrs_corpus_register",
     "hrs_corpus_release",
     "hrs_corpus_shadow",
@@ -69,6 +70,7 @@ def lib():
             "hrs_last_error": ([C.c_char_p, C.c_size_t], i32),
             "hrs_ctx_create": ([i32, C.POINTER(vp)], i32),
             "hrs_ctx_destroy": ([vp], i32),
+            "hrs_ctx_set_peer": ([vp, vp], i32),
             "hrs_corpus_register": ([vp, vp, i64, i32, i64, vp, C.POINTER(vp)], i32),
             "hrs_corpus_release": ([vp, vp], i32),
             "hrs_corpus_shadow": ([vp, vp, i32, vp], i32),

@@ -110,10 +110,20 @@ extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
     return HRS_OK;
 }
 
+extern "C" int hrs_ctx_set_peer(hrs_ctx* ctx, hrs_ctx* peer) {
+    HRS_REQUIRE(ctx, "hrs_ctx_set_peer: null ctx");
+    HRS_REQUIRE(!peer || peer->device == ctx->device, "hrs_ctx_set_peer: contexts on different devices");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!ctx->scan_done) HRS_CHECK_HIP(hipEventCreateWithFlags(&ctx->scan_done, hipEventDisableTiming));
+    ctx->peer = peer;
+    return HRS_OK;
+}
+
 extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
     if (!ctx) return HRS_OK;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
+    if (ctx->scan_done) (void)hipEventDestroy(ctx->scan_done);
     if (ctx->ws_partial.ptr) hipFree(ctx->ws_partial.ptr);
     if (ctx->ws_mfma.ptr) hipFree(ctx->ws_mfma.ptr);
     if (ctx->ws_keys.ptr) hipFree(ctx->ws_keys.ptr);

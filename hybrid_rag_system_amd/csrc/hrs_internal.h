@@ -46,6 +46,11 @@ struct hrs_ctx {
     hrs_workspace ws_mfma;     // MFMA scan: bf16 queries, maxima, tau, counters, candidate lists
     hrs_workspace ws_keys;     // result keys when the caller asks only for distances / rows
     int64_t* stats_dev = nullptr;  // [8] counters of the last MFMA call
+    // two contexts that serve alternate batches on two streams: each scan waits for the peer's last scan,
+    // so scans never share the matrix pipes with each other, only with the peer's re-score tail
+    hrs_ctx* peer = nullptr;
+    hipEvent_t scan_done = nullptr;
+    bool scan_recorded = false;
     // optional kernel timing (hrs_profile_*): event pairs around the dominant scan kernel
     bool profile = false;
     std::vector<hipEvent_t> ev_start, ev_stop;

@@ -884,6 +884,15 @@ static int launch_scan(MfmaArgs a, bool pre, int qt, const hrs_corpus* c, hipStr
     return launch_scan_qt<KS, TR, I8, 1>(a, pre, st);
 }
 
+// Recorded right after the last scan launch of a call: the peer context's next scan waits for it.
+static int scan_mark_done(hrs_ctx* ctx, hipStream_t st) {
+    if (ctx->scan_done) {
+        HRS_CHECK_HIP(hipEventRecord(ctx->scan_done, st));
+        ctx->scan_recorded = true;
+    }
+    return HRS_OK;
+}
+
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
                     hipStream_t st) {
     if (!c->shadow || ctx->num_cu != HRS_NUM_CU) {
@@ -921,6 +930,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     HRS_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 8 * sizeof(int64_t), st));
 
     const int64_t tiles = (c->N + TR - 1) / TR;
+    if (ctx->peer && ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
     for (int qbase = 0; qbase < B; qbase += BC) {
         const int bc = B - qbase < BC ? B - qbase : BC;
         const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
@@ -1008,6 +1018,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             }
         }
 #undef HRS_SCAN
+        if (qbase + BC >= B && (rc = scan_mark_done(ctx, st))) return rc;
         SelectArgs s;
         s.C = c->C;
         s.Q = Q;

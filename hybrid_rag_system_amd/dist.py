@@ -67,6 +67,10 @@ class HybridPipeline:
 
     def __init__(self, engines, corpus, postings, group=None):
         self.lanes = [(ShardedHybrid(e, corpus, postings, group), torch.cuda.Stream(device=e.device)) for e in engines]
+        # the scans themselves take turns: each engine's scan waits for the previous engine's
+        for j, e in enumerate(engines):
+            if len(engines) > 1:
+                e.set_peer(engines[j - 1])
         self.n = 0
 
     def submit(self, queries, q_terms, q_term_offs, n, **kw):

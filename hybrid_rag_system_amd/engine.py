@@ -146,6 +146,10 @@ class Engine:
             self._ctx = None
 
     # ---- registration -------------------------------------------------------------------------
+    def set_peer(self, other):
+        """Scans launched through this engine wait for the last scan launched through `other` (see HybridPipeline)."""
+        N.check(N.lib().hrs_ctx_set_peer(self._ctx, other._ctx if other is not None else None), "hrs_ctx_set_peer")
+
     def corpus(self, matrix, row_offset=0, shadow="auto"):
         return Corpus(self, matrix, row_offset, shadow)
 

@@ -71,6 +71,12 @@ int hrs_last_error(char* buf, size_t n);
  * the GPU `device` of this process. */
 int hrs_ctx_create(int device, hrs_ctx** out);
 int hrs_ctx_destroy(hrs_ctx* ctx);
+/* Two contexts on one device that serve alternate query batches on two streams: after this call the
+ * matrix-core scan of a hrs_score_topk on `ctx` first waits (on its stream) for the last scan launched
+ * through `peer`, so the scans run one after the other while everything behind a scan (candidate sort,
+ * exact re-score) overlaps the peer's next scan.  No counterpart in the reference (a single synchronous
+ * process, scripts/chromadb_helper.py:591-684).  peer may be NULL to undo. */
+int hrs_ctx_set_peer(hrs_ctx* ctx, hrs_ctx* peer);
 
 /* ---- corpus: the collection's embedding matrix --------------------------------------------- */
 /* Stands in for the server side of collection.add(...) (scripts/chromadb_helper.py:397-401,
