@@ -269,6 +269,38 @@ def test_sharded_equals_unsharded(eng):
             cp.close()
 
 
+def test_two_stream_pipeline_equals_single_stream(eng):
+    """Alternate batches over two engines / streams (scans chained by hrs_ctx_set_peer): every batch
+    gives what the plain single-stream step gives."""
+    from hybrid_rag_system_amd.dist import HybridPipeline, ShardedHybrid
+    from hybrid_rag_system_amd.engine import Engine
+
+    rng = np.random.default_rng(41)
+    n, d, b, keep, V, L = 80_000, 384, 96, 5, 500, 12
+    C = _unit(rng, n, d)
+    offs, terms = _postings(rng, n, V, L)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
+    m = rng.integers(1, 5, b)
+    qoffs = torch.from_numpy(np.concatenate([[0], np.cumsum(m)]).astype(np.int32)).cuda()
+    qterms = torch.from_numpy(rng.integers(0, V, int(m.sum())).astype(np.int32)).cuda()
+    batches = [torch.from_numpy(_unit(rng, b, d)).cuda() for _ in range(5)]
+    plain = ShardedHybrid(eng, corpus, post, group=False)
+    want = [plain.step(q, qterms, qoffs, keep, mode="mfma") for q in batches]
+    torch.cuda.synchronize()
+    eng2 = Engine(0)
+    pipe = HybridPipeline([eng, eng2], corpus, post, group=False)
+    got = [pipe.submit(q, qterms, qoffs, keep, mode="mfma") for q in batches]
+    pipe.drain()
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for key in ("cand_rows", "cand_dist", "cand_counts", "perm", "combined"):
+            assert torch.equal(w[key], g[key]), key
+    eng.set_peer(None)
+    eng2.close()
+    corpus.close()
+
+
 def test_hybrid_pipeline_vs_oracle(eng):
     rng = np.random.default_rng(41)
     n, d, B, n_keep, V, L = 120_000, 384, 260, 10, 2000, 32
