@@ -21,6 +21,9 @@ EXPORTS = [
     "hrs_ctx_create",
     "hrs_ctx_destroy",
     "hrs_ctx_set_peer",
+    "hrs_tokenizer_create",
+    "hrs_tokenizer_release",
+    "hrs_tokenize",
     "hrs_corpus_register",
     "hrs_corpus_release",
     "hrs_corpus_shadow",
@@ -71,6 +74,9 @@ def lib():
             "hrs_ctx_create": ([i32, C.POINTER(vp)], i32),
             "hrs_ctx_destroy": ([vp], i32),
             "hrs_ctx_set_peer": ([vp, vp], i32),
+            "hrs_tokenizer_create": ([C.c_char_p, i64, i32, i32, i32, C.POINTER(vp)], i32),
+            "hrs_tokenizer_release": ([vp], i32),
+            "hrs_tokenize": ([vp, C.c_char_p, vp, i32, i32, vp, vp, vp, i32], i32),
             "hrs_corpus_register": ([vp, vp, i64, i32, i64, vp, C.POINTER(vp)], i32),
             "hrs_corpus_release": ([vp, vp], i32),
             "hrs_corpus_shadow": ([vp, vp, i32, vp], i32),

@@ -78,6 +78,24 @@ int hrs_ctx_destroy(hrs_ctx* ctx);
  * process, scripts/chromadb_helper.py:591-684).  peer may be NULL to undo. */
 int hrs_ctx_set_peer(hrs_ctx* ctx, hrs_ctx* peer);
 
+/* ---- tokenizer (host code, no GPU) -------------------------------------------------------- */
+/* The tokenisation sentence-transformers performs inside SentenceTransformerEmbeddingFunction
+ * (scripts/chromadb_helper.py:64-66): BERT basic pre-tokenisation + WordPiece over `vocab_utf8`
+ * ('\n'-separated tokens, id = line number; must hold [CLS], [SEP], [UNK]), or, with vocab_utf8 == NULL,
+ * the hash mapping word -> 1000 + FNV-1a(word) % (hash_vocab_size - 1000) used with generated weights.
+ * Rows start with [CLS], end with [SEP] and hold at most max_len ids. */
+typedef struct hrs_tokenizer hrs_tokenizer;
+int hrs_tokenizer_create(const char* vocab_utf8, int64_t vocab_bytes, int hash_vocab_size, int lower, int max_len,
+                         hrs_tokenizer** out);
+int hrs_tokenizer_release(hrs_tokenizer* tok);
+/* texts: UTF-8 bytes of B texts back to back, text b = [offs[b], offs[b+1]).  Host outputs: ids int32
+ * [B, row_stride] (row_stride >= max_len, padded with the pad id), lens int32 [B], fallback uint8 [B]:
+ * 1 marks a text holding a code point whose lower-casing or normalisation depends on context (final
+ * sigma, U+0130, reorderable marks); its row is empty and the caller tokenises it with the Python
+ * implementation.  `threads` host threads share the texts. */
+int hrs_tokenize(hrs_tokenizer* tok, const char* texts, const int64_t* offs, int B, int row_stride, int32_t* ids,
+                 int32_t* lens, uint8_t* fallback, int threads);
+
 /* ---- corpus: the collection's embedding matrix --------------------------------------------- */
 /* Stands in for the server side of collection.add(...) (scripts/chromadb_helper.py:397-401,
  * 462-466, 474-478): C_dev is the fp32 [N, D] row-major embedding matrix of this shard, row i
