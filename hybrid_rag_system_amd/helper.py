@@ -168,8 +168,8 @@ def add_document(content, metadata=None, doc_id=None, collection_name=None):
         return {"status": "error", "error": str(e)}
 
 
-def index_file(filepath, collection_name=None, chunk=True):
-    """scripts/chromadb_helper.py:407-481: one collection.add per file."""
+def _prepare_file(filepath, chunk=True):
+    """Read and chunk one file -> (path, docs, metas, ids, n_chunks) or an error dict (scripts/chromadb_helper.py:407-459)."""
     path = Path(filepath)
     if not path.exists():
         return {"status": "error", "error": f"File not found: {filepath}"}
@@ -177,7 +177,6 @@ def index_file(filepath, collection_name=None, chunk=True):
         content = path.read_text(encoding="utf-8", errors="ignore")
     except Exception as e:
         return {"status": "error", "error": f"Failed to read file: {e}"}
-    collection = get_collection(collection_name)
     base = {"source": path.name, "filepath": str(path.absolute()), "file_type": path.suffix.lstrip("."), "indexed_at": _now()}
     base.update(extract_metadata_from_content(content, str(path)))
     if chunk and len(content) > CHUNK_SIZE:
@@ -189,30 +188,59 @@ def index_file(filepath, collection_name=None, chunk=True):
     else:
         chunks = [None]
         ids, metas, docs = [generate_doc_id(content, str(path))], [base], [content]
+    return (path, docs, metas, ids, len(chunks))
+
+
+def index_file(filepath, collection_name=None, chunk=True, _prepared=None, _embeddings=None):
+    """scripts/chromadb_helper.py:407-481: one collection.add per file."""
+    prep = _prepared if _prepared is not None else _prepare_file(filepath, chunk)
+    if isinstance(prep, dict):
+        return prep
+    path, docs, metas, ids, n_chunks = prep
+    collection = get_collection(collection_name)
     try:
-        collection.add(documents=docs, metadatas=metas, ids=ids)
-        return {"status": "success", "chunks": len(chunks), "filepath": str(path)}
+        if _embeddings is None:
+            collection.add(documents=docs, metadatas=metas, ids=ids)  # the reference's call, verbatim
+        else:
+            collection.add(documents=docs, metadatas=metas, ids=ids, embeddings=_embeddings)
+        return {"status": "success", "chunks": n_chunks, "filepath": str(path)}
     except Exception as e:
         return {"status": "error", "error": str(e)}
 
 
 def index_directory(directory, patterns=None, collection_name=None, recursive=True):
-    """scripts/chromadb_helper.py:484-529."""
+    """scripts/chromadb_helper.py:484-529.  Same files, order, ids and per-file results as indexing them
+    one by one; the chunks of all files are embedded together (full encoder batches) before the per-file
+    collection.add calls, which then receive their embeddings."""
     if patterns is None:
         patterns = ["*.md", "*.txt", "*.yaml", "*.yml", "*.json"]
     root = Path(directory)
     if not root.exists():
         return {"status": "error", "error": f"Directory not found: {directory}"}
     results = {"status": "success", "indexed": 0, "failed": 0, "files": []}
-    for pattern in patterns:
-        for filepath in (root.rglob(pattern) if recursive else root.glob(pattern)):
-            r = index_file(str(filepath), collection_name)
-            if r["status"] == "success":
-                results["indexed"] += 1
-                results["files"].append({"path": str(filepath), "chunks": r.get("chunks", 1)})
-            else:
-                results["failed"] += 1
-                print(f"  Failed: {filepath}: {r.get('error', 'unknown')}")
+    files = [fp for pattern in patterns for fp in (root.rglob(pattern) if recursive else root.glob(pattern))]
+    prepared = [_prepare_file(str(fp)) for fp in files]
+    embeddings = None
+    try:
+        ef = get_collection(collection_name)._ef
+        if hasattr(ef, "embed_tensor"):
+            texts = [d for p in prepared if not isinstance(p, dict) for d in p[1]]
+            embeddings = ef.embed_tensor(texts).cpu().numpy() if texts else None
+    except Exception:
+        embeddings = None  # the per-file adds embed for themselves and report their own errors
+    at = 0
+    for filepath, prep in zip(files, prepared):
+        emb = None
+        if not isinstance(prep, dict) and embeddings is not None:
+            emb = embeddings[at : at + len(prep[1])]
+            at += len(prep[1])
+        r = index_file(str(filepath), collection_name, _prepared=prep, _embeddings=emb)
+        if r["status"] == "success":
+            results["indexed"] += 1
+            results["files"].append({"path": str(filepath), "chunks": r.get("chunks", 1)})
+        else:
+            results["failed"] += 1
+            print(f"  Failed: {filepath}: {r.get('error', 'unknown')}")
     return results
 
 

@@ -38,7 +38,7 @@ class HrsEmbeddingFunction:
     model; without it the generated weights and the hash tokeniser are used (no hub access exists).
     """
 
-    def __init__(self, model_name="all-MiniLM-L6-v2", model_dir=None, seed=2026, batch_size=256):
+    def __init__(self, model_name="all-MiniLM-L6-v2", model_dir=None, seed=2026, batch_size=1024):
         self.model_name = model_name
         self.cfg = W.EncoderConfig()
         model_dir = model_dir or os.environ.get("HRS_MODEL_DIR")
@@ -183,7 +183,16 @@ class Collection:
             self.ids.append(ids[j])
             self.documents.append(documents[j])
             self.metadatas.append(metadatas[j])
-        self._emb = np.concatenate([self._emb, np.ascontiguousarray(emb, np.float32)])
+        # rows live in a buffer that doubles, so a long run of small adds stays linear
+        need = first + emb.shape[0]
+        buf = getattr(self, "_buf", None)
+        if buf is None or buf.shape[1] != emb.shape[1] or buf.shape[0] < need or buf[:first].base is not self._emb.base and not np.shares_memory(buf, self._emb):
+            cap = max(need, 2 * first, 1024)
+            nb = np.empty((cap, emb.shape[1]), np.float32)
+            nb[:first] = self._emb
+            self._buf = buf = nb
+        buf[first:need] = emb
+        self._emb = buf[:need]
         self._corpus = None
         self._append_to_disk(first)
 

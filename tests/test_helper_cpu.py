@@ -192,3 +192,16 @@ def test_hash_tokenizer_is_stable():
     assert a[0] == 101 and a[-1] == 102 and len(a) == 9 and all(1000 <= x < 30522 for x in a[1:-1])
     assert a == t.encode("restart  THE nginx container , please !")
     assert len(t.encode("word " * 1000)) == 256
+
+
+def test_clean_text_equals_the_regex_form():
+    """clean_text uses str.split(); the reference uses re.sub(r"\\s+", " ", ...) (chromadb_helper.py:93-99)."""
+    import re
+
+    from hybrid_rag_system_amd.textproc import clean_text
+
+    ws = re.compile(r"\s+")
+    for cp in list(range(0x3100)) + [0xFEFF, 0x1D7FF, 0xE0020]:
+        ch = chr(cp)
+        for t in (f"a{ch}b", f"{ch}a {ch}{ch} b{ch}", f"\x00{ch} a", ch):
+            assert clean_text(t) == ws.sub(" ", t).replace("\x00", "").strip(), hex(cp)
