@@ -452,20 +452,37 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
 __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ C, int64_t N, int D, int64_t Npad,
                                                       int Dpad, __bf16* __restrict__ out,
                                                       unsigned long long* __restrict__ stats) {
+    // 16 rows per workgroup (4 per wave): one pair of global atomics per workgroup
+    __shared__ unsigned long long nmin, nmax;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= Npad) return;
-    double ss = 0.0;
-    for (int c = lane; c < Dpad; c += 64) {
-        float v = (r < N && c < D) ? C[r * D + c] : 0.f;
-        out[r * Dpad + c] = (__bf16)v;
-        ss += (double)v * (double)v;
+    if (threadIdx.x == 0) {
+        nmin = ~0ull;
+        nmax = 0ull;
     }
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if (lane == 0 && r < N) {
-        // non-negative doubles order like their bit patterns
-        atomicMin(&stats[0], (unsigned long long)__double_as_longlong(ss));
-        atomicMax(&stats[1], (unsigned long long)__double_as_longlong(ss));
+    __syncthreads();
+    bool any = false;
+    for (int j = 0; j < 4; ++j) {
+        const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + j;
+        if (r >= Npad) break;
+        double ss = 0.0;
+        for (int c = lane; c < Dpad; c += 64) {
+            float v = (r < N && c < D) ? C[r * D + c] : 0.f;
+            out[r * Dpad + c] = (__bf16)v;
+            ss += (double)v * (double)v;
+        }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0 && r < N) {
+            // non-negative doubles order like their bit patterns
+            atomicMin(&nmin, (unsigned long long)__double_as_longlong(ss));
+            atomicMax(&nmax, (unsigned long long)__double_as_longlong(ss));
+            any = true;
+        }
+    }
+    (void)any;
+    __syncthreads();
+    if (threadIdx.x == 0 && (int64_t)blockIdx.x * 16 < N) {
+        atomicMin(&stats[0], nmin);
+        atomicMax(&stats[1], nmax);
     }
 }
 
@@ -479,9 +496,14 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
                                                          unsigned long long* __restrict__ stats) {
     __shared__ float red[4];
     __shared__ int l1max;
+    __shared__ unsigned long long nmin, nmax;  // squared norms as bit patterns (non-negative doubles order like them)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t g = blockIdx.x, r0 = g * 32;
-    if (threadIdx.x == 0) l1max = 0;
+    if (threadIdx.x == 0) {
+        l1max = 0;
+        nmin = ~0ull;
+        nmax = 0ull;
+    }
     float mxv = 0.f;
     for (int rr = wv; rr < 32; rr += 4) {
         const int64_t r = r0 + rr;
@@ -521,13 +543,17 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
             ss += __shfl_xor(ss, o);
         }
         if (lane == 0 && r < N) {
-            atomicMin(&stats[0], (unsigned long long)__double_as_longlong(ss));
-            atomicMax(&stats[1], (unsigned long long)__double_as_longlong(ss));
+            atomicMin(&nmin, (unsigned long long)__double_as_longlong(ss));
+            atomicMax(&nmax, (unsigned long long)__double_as_longlong(ss));
             atomicMax(&l1max, l1);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (r0 < N) {  // one pair of global atomics per group, not per row
+            atomicMin(&stats[0], nmin);
+            atomicMax(&stats[1], nmax);
+        }
         const float mg = (float)I8_EMAX * (float)l1max * 1.000001f + 0.01f;  // rounded up
         // an all-zero group scores exactly 0: a huge reciprocal keeps it out for any positive threshold
         pre_pair[g] = make_float2(gs, mg);
@@ -580,7 +606,7 @@ int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st) {
         hipLaunchKernelGGL(k_build_shadow_i8, dim3((unsigned)groups), dim3(256), 0, st, c->C, c->N, c->D, c->Dpad,
                            (int8_t*)c->shadow, c->group_pre, c->group_main, (unsigned long long*)c->norm_stats);
     } else {
-        hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)((c->Npad + 3) / 4)), dim3(256), 0, st, c->C, c->N, c->D,
+        hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)((c->Npad + 15) / 16)), dim3(256), 0, st, c->C, c->N, c->D,
                            c->Npad, c->Dpad, (__bf16*)c->shadow, (unsigned long long*)c->norm_stats);
     }
     HRS_CHECK_HIP(hipGetLastError());
