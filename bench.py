@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
-    ap.add_argument("--streams", type=int, default=2, help="consecutive batches alternate over this many HIP streams (1: strictly back to back)")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3], help="consecutive batches alternate over this many HIP streams (1: strictly back to back)")
     ap.add_argument("--layout", default="auto", choices=["auto", "replica", "shard"], help="multi-GPU layout (auto: replica when the corpus fits one GPU with room to spare)")
     ap.add_argument("--shadow", default="auto", choices=["auto", "i8", "bf16"], help="scan shadow of the corpus (auto: int8 up to depth 512)")
     ap.add_argument("--no-extras", action="store_true", help="skip the embed / small-batch scan side measurements")

@@ -58,7 +58,9 @@ struct MfmaArgs {
     int64_t tiles;         // ceil(N / TR)
     int64_t row_offset;
     int nqg;               // query groups of 256 (1, 2 or 4); nslices = 256 / nqg
-    int ss;                // sampling stride of the PRE pass (tiles)
+    int ss;                // sampling stride of the sampled passes (tiles)
+    const float* lad_inv;  // ladder pass: per query 16 / (largest sampled score - tau)
+    int* hist;             // ladder pass: [Bpad][16] sampled scores above tau, by sixteenth of that range
     float* maxima;         // [Bpad][HRS_MAX_STREAMS]
     const float* tau;      // [Bpad]
     int* cnt;              // [Bpad]
@@ -74,8 +76,12 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     return x;
 }
 
-template <int KS, int TR, bool PRE, int QT, bool I8>
+// MODE 0: the whole corpus, rows above tau are recorded.  MODE 1: sampled tiles, per (query, stream)
+// running maximum.  MODE 2: sampled tiles, per query a 16-bin count of the scores above tau (the "ladder").
+template <int KS, int TR, int MODE, int QT, bool I8>
 __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
+    constexpr bool PRE = MODE != 0;      // sampled pass
+    constexpr bool MAXIMA = MODE == 1, LADDER = MODE == 2;
     typedef typename scan_types<I8>::frag frag_t;
     typedef typename scan_types<I8>::acc acc_t;
     constexpr int MF_QPW = 32 * QT;           // queries per wave
@@ -111,12 +117,13 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         for (int s = 0; s < KS; ++s)
             qf[qt][s] = *(const frag_t*)(a.qb + (size_t)(q0 + qt * 32 + i) * RB + s * 32 + h * 16);
 
-    float tau[QT], kq[QT];
+    float tau[QT], kq[QT], linv[QT];
     float mx[QT][NSUB];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        tau[qt] = PRE ? 0.f : a.tau[q0 + qt * 32 + i];
+        tau[qt] = MAXIMA ? 0.f : a.tau[q0 + qt * 32 + i];
         kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
+        linv[qt] = LADDER ? a.lad_inv[q0 + qt * 32 + i] : 0.f;
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) mx[qt][sb] = -__builtin_inff();
     }
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]));
+    for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]), "+v"(linv[qt]));
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
@@ -263,8 +270,16 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         int m = acc[qt][0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) m = max(m, acc[qt][r]);
-                        if (PRE) {
+                        if (MAXIMA) {
                             mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + kq[qt] + sc[sb].y) * sc[sb].x);  // .x = s_g
+                        } else if (LADDER) {
+                            if (((float)m + kq[qt] + sc[sb].y) * sc[sb].x > tau[qt]) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float v = ((float)acc[qt][r] + kq[qt] + sc[sb].y) * sc[sb].x;
+                                    if (v > tau[qt]) atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + min(15, (int)((v - tau[qt]) * linv[qt]))], 1);
+                                }
+                            }
                         } else {
                             // s_g (acc + K_q + M_g) > tau  <=>  acc > tau / s_g - K_q - M_g; the threshold is
                             // pushed down by more than the rounding of these few operations, so that no
@@ -286,8 +301,15 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         float m = acc[qt][0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qt][r]);
-                        if (PRE) {
+                        if (MAXIMA) {
                             mx[qt][sb] = fmaxf(mx[qt][sb], m);
+                        } else if (LADDER) {
+                            if (m > tau[qt]) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    if (acc[qt][r] > tau[qt])
+                                        atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + min(15, (int)((acc[qt][r] - tau[qt]) * linv[qt]))], 1);
+                            }
                         } else if (m > tau[qt]) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
@@ -299,7 +321,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (PRE) {
+    if (MAXIMA) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -324,8 +346,9 @@ __device__ __forceinline__ void mfma_result_fence(f32x16& acc) {  // 8-pass MFMA
     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
 }
 
-template <bool PRE>
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
+    constexpr bool PRE = MODE != 0, MAXIMA = MODE == 1, LADDER = MODE == 2;
     constexpr int DP = 1024, KC = 512, SPT = 2, KSS = 32, ROWB = KC * 2, STAGE = 32 * ROWB, IPW = 8, NBUF = 4, NA = 56;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -341,7 +364,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
     bf16x8 qf[SPT * KSS];
 #pragma unroll
     for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + ((size_t)(q0 + i) * DP + s * 16 + h * 8) * 2);
-    const float tau = PRE ? 0.f : a.tau[q0 + i];
+    const float tau = MAXIMA ? 0.f : a.tau[q0 + i];
+    const float linv = LADDER ? a.lad_inv[q0 + i] : 0.f;
     float mx = -__builtin_inff();
 #pragma unroll
     for (int s = 0; s < SPT * KSS; ++s) {
@@ -423,8 +447,14 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
                 float m = acc[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                if (PRE) {
+                if (MAXIMA) {
                     mx = fmaxf(mx, m);
+                } else if (LADDER) {
+                    if (m > tau) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (acc[r] > tau) atomicAdd(&a.hist[(q0 + i) * 16 + min(15, (int)((acc[r] - tau) * linv))], 1);
+                    }
                 } else if (m > tau) {
                     const int64_t tile = tile_at(g / SPT);
                     const int q = q0 + i;
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (PRE) a.maxima[(size_t)(q0 + i) * HRS_MAX_STREAMS + slice * 2 + h] = mx;
+    if (MAXIMA) a.maxima[(size_t)(q0 + i) * HRS_MAX_STREAMS + slice * 2 + h] = mx;
 }
 
 // fp32 [N, D] -> bf16 [Npad, Dpad] (zero padded) and min/max squared row norm. One wave per row.
@@ -663,9 +693,10 @@ __global__ __launch_bounds__(256) void k_convert_q(const float* __restrict__ Q, 
     if (lane == 0) qn2[q] = ss;
 }
 
-// tau[q] = j-th largest of the query's M stream maxima; also clears the candidate counter.
+// tau[q] = j-th largest of the query's M stream maxima -- for rows that score independently about
+// `target` rows exceed it.  Also: the ladder step 16 / (largest maximum - tau) and cleared counters.
 __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxima, int M, int j, float* __restrict__ tau,
-                                                  int* __restrict__ cnt) {
+                                                  int* __restrict__ cnt, float* __restrict__ lad_inv, int* __restrict__ hist) {
     __shared__ uint64_t s[HRS_MAX_STREAMS];
     const int q = blockIdx.x;
     int n2 = 1;
@@ -675,12 +706,38 @@ __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxi
         s[t] = t < M ? (uint64_t)(~f32_orderable(maxima[(size_t)q * HRS_MAX_STREAMS + t])) : HRS_PAD_KEY;
     }
     bitonic_sort_u64(s, n2, threadIdx.x, 256);
+    if (threadIdx.x < 16) hist[q * 16 + threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         int jj = j < M ? j : M;
-        float v = orderable_f32(~(uint32_t)s[jj - 1]);
+        const float v = orderable_f32(~(uint32_t)s[jj - 1]);
+        const float top = orderable_f32(~(uint32_t)s[0]);
         tau[q] = v;
         cnt[q] = 0;
+        lad_inv[q] = (top > v && top - v < 1e30f) ? 16.0f / (top - v) : 0.f;
     }
+}
+
+// Rows of a topically ordered corpus do not score independently: whole runs of neighbours exceed the
+// first tau together and the candidate lists would overflow.  The ladder pass has counted the sampled
+// scores above tau in sixteen steps up to the largest sampled score; tau moves up to the lowest step
+// above which the estimated number of rows (count x sampling stride) fits `limit`.  It never moves down.
+__global__ void k_raise_tau(float* __restrict__ tau, const float* __restrict__ lad_inv, const int* __restrict__ hist, int B,
+                            int ss, int limit) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B) return;
+    const float li = lad_inv[q];
+    if (li <= 0.f) return;
+    long long above = 0;
+    int step = 0;
+    for (int b = 15; b >= 0; --b) {
+        above += hist[q * 16 + b];
+        if (above * ss > limit) {
+            step = b + 1;  // rows from step b upward are too many: start one step higher
+            break;
+        }
+    }
+    if (step > 15) step = 15;
+    if (step > 0) tau[q] += (float)step / li;
 }
 
 struct SelectArgs {
@@ -748,7 +805,8 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         }
         if (SPACE == HRS_SPACE_L2) return qn + ncmin - 2.0 * sb;
         if (SPACE == HRS_SPACE_IP) return 1.0 - sb;
-        return qn > 0.0 ? 1.0 - sb / (sqrt(qn) * sqrt(sb > 0.0 ? ncmin : ncmax)) : 2.0;
+        // (a zero query is at distance 1 from every row by definition: nothing can be proven, all rows tie)
+        return qn > 0.0 ? 1.0 - sb / (sqrt(qn) * sqrt(sb > 0.0 ? ncmin : ncmax)) : 1.0;
     };
     double nq = 0.0;
     if (SPACE == HRS_SPACE_COSINE) {
@@ -880,20 +938,21 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
 }
 
 template <int KS, int TR, bool I8, int QT>
-static int launch_scan_qt(const MfmaArgs& a, bool pre, hipStream_t st) {
+static int launch_scan_qt(const MfmaArgs& a, int mode, hipStream_t st) {
     const size_t lds = (size_t)HRS_SCAN_NBUF * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, true, QT, I8>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, false, QT, I8>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 0, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 1, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 2, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (pre)
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, true, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+    if (mode == 1)
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 1, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+    else if (mode == 2)
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 2, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     else
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, false, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 0, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
@@ -904,10 +963,10 @@ template <int KS, bool I8>
 constexpr int scan_qt_max() { return (I8 && KS <= 12) ? 2 : 1; }
 
 template <int KS, int TR, bool I8>
-static int launch_scan(MfmaArgs a, bool pre, int qt, const hrs_corpus* c, hipStream_t st) {
-    a.group = pre ? c->group_pre : c->group_main;
-    if (qt == 2 && scan_qt_max<KS, I8>() == 2) return launch_scan_qt<KS, TR, I8, scan_qt_max<KS, I8>()>(a, pre, st);
-    return launch_scan_qt<KS, TR, I8, 1>(a, pre, st);
+static int launch_scan(MfmaArgs a, int mode, int qt, const hrs_corpus* c, hipStream_t st) {
+    a.group = mode == 0 ? c->group_main : c->group_pre;
+    if (qt == 2 && scan_qt_max<KS, I8>() == 2) return launch_scan_qt<KS, TR, I8, scan_qt_max<KS, I8>()>(a, mode, st);
+    return launch_scan_qt<KS, TR, I8, 1>(a, mode, st);
 }
 
 // Recorded right after the last scan launch of a call: the peer context's next scan waits for it.
@@ -946,6 +1005,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_cnt = carve((size_t)BC * sizeof(int));
     const size_t o_qs = carve((size_t)BC * sizeof(float));
     const size_t o_kq = carve((size_t)BC * sizeof(float));
+    const size_t o_lad = carve((size_t)BC * sizeof(float));
+    const size_t o_hist = carve((size_t)BC * 16 * sizeof(int));
     const size_t o_cand = carve((size_t)BC * HRS_CAND_CAP * sizeof(uint64_t));
     int rc = hrs_ws_reserve(ctx, &ctx->ws_mfma, off);
     if (rc) return rc;
@@ -989,6 +1050,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.tau = (const float*)(ws + o_tau);
         a.cnt = (int*)(ws + o_cnt);
         a.cand = (uint64_t*)(ws + o_cand);
+        a.lad_inv = (const float*)(ws + o_lad);
+        a.hist = (int*)(ws + o_hist);
         const int M = nslices * 2 * (TR / 32);
         // aim at ~max(384, 6k) rows above tau; expected count ~ ss * M * -ln(1 - j/M)
         int target = 6 * k > 384 ? 6 * k : 384;
@@ -996,28 +1059,48 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         if (j < 16) j = 16;
         if (j > M / 2) j = M / 2;
 
-#define HRS_SCAN(KS_, TR_, I8_)                                \
-    case KS_:                                                  \
-        rc = launch_scan<KS_, TR_, I8_>(a, true, qt, c, st);   \
-        if (rc) return rc;                                     \
-        hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt); \
-        hrs_prof_begin(ctx, st);                               \
-        rc = launch_scan<KS_, TR_, I8_>(a, false, qt, c, st);  \
-        hrs_prof_end(ctx, st);                                 \
-        if (rc) return rc;                                     \
-        break;
+        // sampled maxima -> first tau -> sampled ladder counts -> tau raised where rows come in runs -> scan
+        auto tau_steps = [&](auto&& scan) -> int {
+            int r = scan(1);
+            if (r) return r;
+            hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt,
+                               (float*)(ws + o_lad), (int*)(ws + o_hist));
+            r = scan(2);
+            if (r) return r;
+            hipLaunchKernelGGL(k_raise_tau, dim3((bpad + 255) / 256), dim3(256), 0, st, (float*)(ws + o_tau),
+                               (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss, HRS_CAND_CAP / 2);
+            return HRS_OK;
+        };
+#define HRS_SCAN(KS_, TR_, I8_)                                                                      \
+    case KS_: {                                                                                      \
+        auto scan = [&](int mode) { return launch_scan<KS_, TR_, I8_>(a, mode, qt, c, st); };        \
+        if ((rc = tau_steps(scan))) return rc;                                                       \
+        hrs_prof_begin(ctx, st);                                                                     \
+        rc = scan(0);                                                                                \
+        hrs_prof_end(ctx, st);                                                                       \
+        if (rc) return rc;                                                                           \
+    } break;
         if (wide) {
             static bool attr_set = false;
             const int lds = 4 * 32 * 1024;
             if (!attr_set) {
-                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(k_mfma_scan_wide<true>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
-            hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt);
+            auto scan = [&](int mode) {
+                if (mode == 1)
+                    hipLaunchKernelGGL(k_mfma_scan_wide<1>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
+                else if (mode == 2)
+                    hipLaunchKernelGGL(k_mfma_scan_wide<2>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
+                else
+                    hipLaunchKernelGGL(k_mfma_scan_wide<0>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
+                return (int)HRS_OK;
+            };
+            if ((rc = tau_steps(scan))) return rc;
             hrs_prof_begin(ctx, st);
-            hipLaunchKernelGGL(k_mfma_scan_wide<false>, dim3(HRS_NUM_CU), dim3(256), lds, st, a);
+            scan(0);
             hrs_prof_end(ctx, st);
             HRS_CHECK_HIP(hipGetLastError());
         } else if (i8) {

@@ -173,6 +173,28 @@ def test_mfma_awkward_rows(eng, space, shadow):
 
 
 @pytest.mark.parametrize("shadow", ["i8", "bf16"])
+def test_mfma_topically_ordered_corpus(eng, shadow):
+    """Rows that come in runs of near neighbours (documents indexed file by file): scores are not
+    independent, whole runs exceed a threshold together.  The sampled ladder count raises the threshold
+    so that the candidate lists do not overflow, and the results stay exact."""
+    rng = np.random.default_rng(5)
+    d, csize, ncl = 384, 500, 160
+    centers = _unit(rng, ncl, d)
+    C = np.repeat(centers, csize, axis=0) + (0.3 / np.sqrt(d)) * rng.standard_normal((ncl * csize, d)).astype(np.float32)
+    C = (C / np.linalg.norm(C, axis=1, keepdims=True)).astype(np.float32)
+    Q = centers[rng.integers(0, ncl, 48)] + (0.1 / np.sqrt(d)) * rng.standard_normal((48, d)).astype(np.float32)
+    Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    want = so.topk_keys(Q, C, 10, "l2")
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), 10, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    assert np.array_equal(_keys(keys), want), st
+    assert st["overflow_queries"] == 0 and st["fallback_queries"] <= 2, st
+    corpus.close()
+
+
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
 def test_mfma_fallback_on_heavy_ties(eng, shadow):
     """More exact duplicates of the best row than the largest re-score window: the proof fails and the
     query is answered by the exact scan, still bit-exact.  A second query has more duplicates than the
