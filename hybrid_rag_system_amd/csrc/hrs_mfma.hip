@@ -1065,10 +1065,14 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             if (r) return r;
             hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt,
                                (float*)(ws + o_lad), (int*)(ws + o_hist));
+            // the ladder only has to be right within a factor of two: half the sample of the first pass
+            const int ss2 = (int64_t)2 * ss * 4 <= min_len ? 2 * ss : ss;
+            a.ss = ss2;
             r = scan(2);
+            a.ss = ss;
             if (r) return r;
             hipLaunchKernelGGL(k_raise_tau, dim3((bpad + 255) / 256), dim3(256), 0, st, (float*)(ws + o_tau),
-                               (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss, HRS_CAND_CAP / 2);
+                               (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss2, HRS_CAND_CAP / 2);
             return HRS_OK;
         };
 #define HRS_SCAN(KS_, TR_, I8_)                                                                      \
