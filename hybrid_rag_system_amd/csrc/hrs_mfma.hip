@@ -261,8 +261,8 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         if (row < a.N) {
                             const int q = q0 + qt * 32 + i;
                             const int pos = atomicAdd(&a.cnt[q], 1);
-                            if (pos < HRS_CAND_CAP)
-                                a.cand[(size_t)q * HRS_CAND_CAP + pos] =
+                            if (pos < HRS_CAND_CAP_BIG)
+                                a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] =
                                     ((uint64_t)(~f32_orderable(score)) << 32) | (uint32_t)(row + a.row_offset);
                         }
                     };
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
                             const int64_t row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                             if (row < a.N) {
                                 const int pos = atomicAdd(&a.cnt[q], 1);
-                                if (pos < HRS_CAND_CAP)
-                                    a.cand[(size_t)q * HRS_CAND_CAP + pos] =
+                                if (pos < HRS_CAND_CAP_BIG)
+                                    a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] =
                                         ((uint64_t)(~f32_orderable(acc[r])) << 32) | (uint32_t)(row + a.row_offset);
                             }
                         }
@@ -759,34 +759,51 @@ struct SelectArgs {
     uint64_t* keys_out;  // [B][k]
     int32_t* qlist;      // queue of queries for the exact fallback
     int32_t* nflag;
+    int32_t* qlist2;     // queue (chunk-local indices) of queries deferred to the large variant; [0] of nflag2 = count
+    int32_t* nflag2;
     long long* stats;    // [0] fallbacks, [1] max candidates, [2] overflows
     int qbase;           // first query of this chunk
 };
 
-#define HRS_RESCORE_MAX 1024  // the re-scored prefix grows in rounds of HRS_RESCORE up to this many
+// Two sizes of the same kernel.  The small one (lists up to HRS_CAND_CAP, re-scored prefix up to 1024
+// rows, three workgroups per CU) serves every query first; a query whose list is longer or whose
+// prefix would have to grow further -- runs of near-duplicate rows around the top -- is deferred to the
+// large one (lists up to HRS_CAND_CAP_BIG, prefix up to 4096, one workgroup per CU), and only what that
+// cannot prove goes to the exact scan.
 
 // Per query: sort the candidates by their recorded score (an upper bound of the true score up to the
 // shadow's error term), re-score the best HRS_RESCORE exactly, and extend the re-scored prefix while any
 // candidate outside it could still beat the current k-th exact distance.  Accept when nothing outside
 // the prefix -- recorded or never recorded (score <= tau) -- can; otherwise queue the query for the
 // exact scan.
-template <int SPACE>
+template <int SPACE, bool BIG>
 __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
-    __shared__ uint64_t s[HRS_CAND_CAP];
-    __shared__ uint64_t ek[HRS_RESCORE_MAX];
-    __shared__ __attribute__((aligned(16))) float qs[1024];  // the query (D <= 1024 on this path)
-    __shared__ __attribute__((aligned(16))) char stage[4 * 64 * 144];  // per wave: 64 rows x one 128-byte line (+16 pad)
+    constexpr int SCAP = BIG ? HRS_CAND_CAP_BIG : HRS_CAND_CAP;  // candidates sorted in LDS
+    constexpr int RMAX = BIG ? 4096 : 1024;                      // largest re-scored prefix
+    extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+    uint64_t* s = (uint64_t*)sel_smem;                       // [SCAP]
+    uint64_t* ek = s + SCAP;                                 // [RMAX]
+    float* qs = (float*)(ek + RMAX);                         // [1024] the query (D <= 1024 on this path)
+    char* stage = (char*)(qs + 1024);                        // per wave: 64 rows x one 128-byte line (+16 pad)
     __shared__ int need_s, ok;
-    const int ql = blockIdx.x;       // query within the chunk
+    int ql = blockIdx.x;             // query within the chunk
+    if (BIG) {
+        if ((int)blockIdx.x >= *a.nflag2) return;
+        ql = a.qlist2[blockIdx.x];
+    }
     const int q = a.qbase + ql;      // query in the caller's batch
     const int tid = threadIdx.x;
     const int craw = a.cnt[ql];
-    const int c = craw < HRS_CAND_CAP ? craw : HRS_CAND_CAP;
-    const bool overflow = craw > HRS_CAND_CAP;
+    const int c = craw < SCAP ? craw : SCAP;
+    const bool overflow = craw > HRS_CAND_CAP_BIG;  // rows above tau were dropped: only the exact scan can answer
+    if (!BIG && craw > SCAP && !overflow) {         // longer than this variant sorts: the large one takes it
+        if (tid == 0) a.qlist2[atomicAdd(a.nflag2, 1)] = ql;
+        return;
+    }
     int n2 = 256;
     while (n2 < c) n2 <<= 1;
-    for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP + t] : HRS_PAD_KEY;
-    for (int t = tid; t < HRS_RESCORE_MAX; t += 256) ek[t] = HRS_PAD_KEY;
+    for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP_BIG + t] : HRS_PAD_KEY;
+    for (int t = tid; t < RMAX; t += 256) ek[t] = HRS_PAD_KEY;
     const float* qr = a.Q + (size_t)q * a.D;
     for (int t = tid; t < a.D; t += 256) qs[t] = qr[t];
     bitonic_sort_u64(s, n2, tid, 256);
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     }
     int done = 0;                       // candidates [0, done) are re-scored
     int want = c < HRS_RESCORE ? c : HRS_RESCORE;
-    bool accept = false;
+    bool accept = false, defer = false;
     while (true) {
         // Re-score candidates [done, want): thread t owns candidate done + t (one fp64 chain per row, the
         // oracle's operation order).  The rows are fetched by the wave together -- eight lanes per row, a
@@ -897,7 +914,11 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         }
         done = want;
         if (tid == 0) need_s = 0;
-        bitonic_sort_u64(ek, done <= 256 ? 256 : (done <= 512 ? 512 : HRS_RESCORE_MAX), tid, 256);  // (its barriers also publish need_s)
+        {
+            int en = 256;
+            while (en < done) en <<= 1;
+            bitonic_sort_u64(ek, en, tid, 256);  // (its barriers also publish need_s)
+        }
         if (overflow || done < a.k) break;
         const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
         // recorded scores are sorted descending, so the candidates that could still beat dk are a prefix
@@ -917,16 +938,21 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
             accept = dk + 1e-6 * (1.0 + fabs(dmin)) < dmin;
             break;
         }
-        if (done >= HRS_RESCORE_MAX) break;
+        if (done >= RMAX) {
+            defer = !BIG;  // the large variant may re-score four times as many
+            break;
+        }
         want = need < done + HRS_RESCORE ? need : done + HRS_RESCORE;
-        if (want > HRS_RESCORE_MAX) want = HRS_RESCORE_MAX;
+        if (want > RMAX) want = RMAX;
     }
     if (tid == 0) {
         ok = accept;
         atomicMax((unsigned long long*)&a.stats[1], (unsigned long long)craw);
         if (overflow) atomicAdd((unsigned long long*)&a.stats[2], 1ull);
         if (done > HRS_RESCORE) atomicAdd((unsigned long long*)&a.stats[3], 1ull);
-        if (!accept) {
+        if (defer) {
+            a.qlist2[atomicAdd(a.nflag2, 1)] = ql;
+        } else if (!accept) {
             atomicAdd((unsigned long long*)&a.stats[0], 1ull);
             const int p = atomicAdd(a.nflag, 1);
             a.qlist[p] = q;
@@ -969,6 +995,23 @@ static int launch_scan(MfmaArgs a, int mode, int qt, const hrs_corpus* c, hipStr
     return launch_scan_qt<KS, TR, I8, 1>(a, mode, st);
 }
 
+template <int SPACE>
+static int launch_select(const SelectArgs& s, int bc, hipStream_t st) {
+    const int lds_small = (HRS_CAND_CAP + 1024) * 8 + 1024 * 4 + 4 * 64 * 144;
+    const int lds_big = (HRS_CAND_CAP_BIG + 4096) * 8 + 1024 * 4 + 4 * 64 * 144;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_select_rescore<SPACE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_select_rescore<SPACE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_select_rescore<SPACE, false>), dim3(bc), dim3(256), lds_small, st, s);
+    // deferred queries (device-side count; workgroups beyond it leave at once)
+    hipLaunchKernelGGL((k_select_rescore<SPACE, true>), dim3(bc), dim3(256), lds_big, st, s);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
 // Recorded right after the last scan launch of a call: the peer context's next scan waits for it.
 static int scan_mark_done(hrs_ctx* ctx, hipStream_t st) {
     if (ctx->scan_done) {
@@ -1007,7 +1050,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_kq = carve((size_t)BC * sizeof(float));
     const size_t o_lad = carve((size_t)BC * sizeof(float));
     const size_t o_hist = carve((size_t)BC * 16 * sizeof(int));
-    const size_t o_cand = carve((size_t)BC * HRS_CAND_CAP * sizeof(uint64_t));
+    const size_t o_cand = carve((size_t)BC * HRS_CAND_CAP_BIG * sizeof(uint64_t));
+    const size_t o_q2 = carve((size_t)BC * sizeof(int32_t) + 256);
     int rc = hrs_ws_reserve(ctx, &ctx->ws_mfma, off);
     if (rc) return rc;
     char* ws = (char*)ctx->ws_mfma.ptr;
@@ -1152,12 +1196,16 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.nflag = nflag;
         s.stats = (long long*)ctx->stats_dev;
         s.qbase = qbase;
+        s.qlist2 = (int32_t*)(ws + o_q2) + 64;
+        s.nflag2 = (int32_t*)(ws + o_q2);
+        HRS_CHECK_HIP(hipMemsetAsync(s.nflag2, 0, sizeof(int32_t), st));
         if (space == HRS_SPACE_L2)
-            hipLaunchKernelGGL(k_select_rescore<HRS_SPACE_L2>, dim3(bc), dim3(256), 0, st, s);
+            rc = launch_select<HRS_SPACE_L2>(s, bc, st);
         else if (space == HRS_SPACE_COSINE)
-            hipLaunchKernelGGL(k_select_rescore<HRS_SPACE_COSINE>, dim3(bc), dim3(256), 0, st, s);
+            rc = launch_select<HRS_SPACE_COSINE>(s, bc, st);
         else
-            hipLaunchKernelGGL(k_select_rescore<HRS_SPACE_IP>, dim3(bc), dim3(256), 0, st, s);
+            rc = launch_select<HRS_SPACE_IP>(s, bc, st);
+        if (rc) return rc;
         HRS_CHECK_HIP(hipGetLastError());
     }
     // queries that could not be proven take the exact scan (device-side count; usually zero)
