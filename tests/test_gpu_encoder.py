@@ -69,3 +69,24 @@ def test_padding_does_not_leak(setup):
         ids2[b, lens[b]:] = rng.integers(1000, 30000, 128 - lens[b])
     b2 = enc.encode_ids(torch.from_numpy(ids2).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
     assert np.array_equal(a, b2)
+
+
+def test_full_batch_is_batch_invariant(setup):
+    """Config 3's shape (1024 sequences x 256 tokens): unit rows, and the same rows whatever the batch
+    they travel in (a sequence's result depends on nothing but its own tokens), bit for bit."""
+    eng, enc, w, cfg = setup
+    ids, lens = _inputs(1024, 256, seed=77)
+    dids, dlens = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    full = enc.encode_ids(dids, dlens)
+    norms = full.norm(dim=1)
+    assert torch.isfinite(full).all() and (norms - 1).abs().max().item() < 1e-5
+    parts = torch.cat([enc.encode_ids(dids[s : s + 256].contiguous(), dlens[s : s + 256].contiguous()) for s in range(0, 1024, 256)])
+    assert torch.equal(full, parts)
+    again = enc.encode_ids(dids, dlens)
+    assert torch.equal(full, again)
+    # and a sample of it against the fp32 oracle
+    sel = [0, 1, 2, 511, 1023]
+    want = EO.forward(w, ids[sel], lens[sel], cfg).numpy()
+    got = full[sel].cpu().numpy()
+    cos = (want * got).sum(1) / (np.linalg.norm(want, axis=1) * np.linalg.norm(got, axis=1))
+    assert cos.min() >= COS_TOL, cos
