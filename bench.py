@@ -140,6 +140,37 @@ def bench_scan(eng, corpus, queries, k=10):
     return out
 
 
+def bench_other_configs(eng):
+    """BASELINE configs 2 and 5 on one GPU: plain exact top-k scoring (no keyword stage), MFMA path."""
+    out = {}
+    for name, n, D, B, k in (("config2_1Mx384_cosine_top10_batch256", 1_000_000, 384, 256, 10),
+                             ("config5_one_shard_12.5Mx1024_cosine_top100_batch1024", 12_500_000, 1024, 1024, 100)):
+        m = torch.empty((n, D), dtype=torch.float32, device=eng.device)
+        for r0 in range(0, n, 1 << 20):
+            nr = min(1 << 20, n - r0)
+            eng.synth_rows(SEED_CORPUS + 5, r0, nr, D, out=m[r0 : r0 + nr])
+        c = eng.corpus(m)
+        q = eng.synth_rows(SEED_QUERY + 5, 0, B, D)
+        eng.score_topk(c, q, k, space="cosine", mode="mfma")
+        torch.cuda.synchronize()
+        st = eng.score_stats()
+        eng.profile(True)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.score_topk(c, q, k, space="cosine", mode="mfma")
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ms, nl = eng.profile_read()
+        eng.profile(False)
+        out[name] = {"ms_per_batch": dt * 1e3, "queries_per_s": B / dt, "scan_kernel_ms": ms / max(nl, 1),
+                     "scan_TFLOPs": 2.0 * n * D * B / (ms / max(nl, 1) * 1e-3) / 1e12, "fallback_queries": st["fallback_queries"]}
+        c.close()
+        del m, c
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,6 +326,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             line["extras"] = {"embed": bench_embed(eng), "exact_scan": bench_scan(eng, corpus, queries)}
+            line["extras"].update(bench_other_configs(eng))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(matrix, terms, queries, q_terms, q_offs, n_keep, n_total, args.cpu_sample_rows, args.cpu_sample_queries)
         else:
