@@ -211,7 +211,6 @@ extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, i
     HRS_REQUIRE(k >= 1 && k <= HRS_MAX_K, "hrs_score_topk: k=%d outside [1, %d]", k, HRS_MAX_K);
     HRS_REQUIRE(space >= 0 && space <= 2, "hrs_score_topk: unknown space %d", space);
     HRS_REQUIRE(mode >= 0 && mode <= 2, "hrs_score_topk: unknown mode %d", mode);
-    HRS_REQUIRE(!(mode == HRS_MODE_MFMA && row_mask_dev), "hrs_score_topk: a row mask needs EXACT mode");
     if (B == 0) return HRS_OK;
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -227,10 +226,10 @@ extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, i
     else if (mode == HRS_MODE_MFMA)
         use_mfma = true;
     else
-        use_mfma = !row_mask_dev && B > 4 && c->N >= 65536;
+        use_mfma = B > 4 && c->N >= 65536;
     if (use_mfma && (c->N < 4096 || c->N < (int64_t)k * 64)) use_mfma = false;
 
-    int rc = use_mfma ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, keys, st)
+    int rc = use_mfma ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st)
                       : hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, st);
     if (rc == HRS_OK && (dist_dev || rows_dev))
         rc = hrs_unpack_keys(ctx, keys, (int64_t)B * k, dist_dev, rows_dev, stream);

@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 // Launchers implemented in the kernel files.
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st);
-int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
-                    hipStream_t st);
+int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
+                    uint64_t* keys_out, hipStream_t st);
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st);
 void hrs_free_shadow(hrs_corpus* c);

@@ -61,6 +61,7 @@ struct MfmaArgs {
     int ss;                // sampling stride of the sampled passes (tiles)
     const float* lad_inv;  // ladder pass: per query 16 / (largest sampled score - tau)
     int* hist;             // ladder pass: [Bpad][16] sampled scores above tau, by sixteenth of that range
+    const uint8_t* mask;   // nullable, [N]: rows with 0 are never recorded (the `where` filter)
     float* maxima;         // [Bpad][HRS_MAX_STREAMS]
     const float* tau;      // [Bpad]
     int* cnt;              // [Bpad]
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 for (int qt = 0; qt < QT; ++qt) {
                     auto append = [&](int r, float score) __attribute__((always_inline)) {
                         const int64_t row = tile * TR + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < a.N) {
+                        if (row < a.N && (!a.mask || a.mask[row])) {
                             const int q = q0 + qt * 32 + i;
                             const int pos = atomicAdd(&a.cnt[q], 1);
                             if (pos < HRS_CAND_CAP_BIG)
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         if (acc[r] > tau) {
                             const int64_t row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if (row < a.N) {
+                            if (row < a.N && (!a.mask || a.mask[row])) {
                                 const int pos = atomicAdd(&a.cnt[q], 1);
                                 if (pos < HRS_CAND_CAP_BIG)
                                     a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] =
@@ -1021,11 +1022,11 @@ static int scan_mark_done(hrs_ctx* ctx, hipStream_t st) {
     return HRS_OK;
 }
 
-int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, uint64_t* keys_out,
-                    hipStream_t st) {
+int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
+                    uint64_t* keys_out, hipStream_t st) {
     if (!c->shadow || ctx->num_cu != HRS_NUM_CU) {
         // no matrix-core kernel for this shape: the exact scan gives the same answer
-        return hrs_launch_exact(ctx, c, Q, B, k, space, nullptr, nullptr, nullptr, keys_out, st);
+        return hrs_launch_exact(ctx, c, Q, B, k, space, mask, nullptr, nullptr, keys_out, st);
     }
     const bool i8 = c->kind == HRS_SHADOW_I8;
     const int Dpad = c->Dpad, KS = i8 ? Dpad / 32 : Dpad / 16;
@@ -1094,6 +1095,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.tau = (const float*)(ws + o_tau);
         a.cnt = (int*)(ws + o_cnt);
         a.cand = (uint64_t*)(ws + o_cand);
+        a.mask = mask;
         a.lad_inv = (const float*)(ws + o_lad);
         a.hist = (int*)(ws + o_hist);
         const int M = nslices * 2 * (TR / 32);
@@ -1209,5 +1211,5 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         HRS_CHECK_HIP(hipGetLastError());
     }
     // queries that could not be proven take the exact scan (device-side count; usually zero)
-    return hrs_launch_exact(ctx, c, Q, B, k, space, nullptr, qlist, nflag, keys_out, st);
+    return hrs_launch_exact(ctx, c, Q, B, k, space, mask, qlist, nflag, keys_out, st);
 }

@@ -116,7 +116,9 @@ int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* corpus, void* stream, double* min
  * (scripts/chromadb_helper.py:259-269 with n, 289-293 with 2n): exact top-k of every query row of
  * Q_dev (fp32 [B, D]) over the corpus, ordered by (fp32 distance ascending, row ascending).
  * row_mask_dev (nullable, uint8 [N]): rows with 0 are skipped -- the `where` filter
- * (scripts/chromadb_helper.py:265-266); a mask forces EXACT mode.
+ * (scripts/chromadb_helper.py:265-266).  The MFMA scan never records a masked row; its thresholds come
+ * from all rows, so a mask that keeps few rows leaves fewer than k candidates and the query takes the
+ * exact scan (same result).
  * Outputs (each nullable): keys_dev uint64 [B, k]; dist_dev fp32 [B, k] (+inf when missing);
  * rows_dev int64 [B, k] global rows (-1 when missing).  1 <= k <= HRS_MAX_K. */
 int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,

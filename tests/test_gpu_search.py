@@ -76,6 +76,30 @@ def test_exact_mask(eng):
     corpus.close()
 
 
+@pytest.mark.parametrize("keep", [0.5, 0.02])
+def test_mfma_with_row_mask(eng, keep):
+    """The `where` filter on the matrix-core path: masked rows are never recorded; a mask that keeps few
+    rows sends queries to the (masked) exact scan.  Same keys as the oracle either way."""
+    rng = np.random.default_rng(8)
+    n, d, b, k = 100_003, 384, 40, 10
+    C = _unit(rng, n, d)
+    Q = _unit(rng, b, d)
+    for j in range(10):
+        Q[j] = C[j * 4999]  # some of these rows are masked out: their duplicates must not come back
+    mask = (rng.random(n) < keep).astype(np.uint8)
+    want = so.topk_keys(Q, C, k, "l2", mask=mask)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    _, rows, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, mask=torch.from_numpy(mask).cuda(), mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    assert np.array_equal(_keys(keys), want), st
+    r = rows.cpu().numpy()
+    assert (mask[r[r >= 0]] == 1).all()
+    if keep == 0.5:
+        assert st["fallback_queries"] <= 3, st
+    corpus.close()
+
+
 def test_empty_corpus(eng):
     corpus = eng.corpus(torch.empty((0, 384), dtype=torch.float32, device="cuda"))
     dist, rows = eng.score_topk(corpus, torch.zeros((2, 384), device="cuda"), 5)
