@@ -121,13 +121,14 @@ extern "C" int hrs_ctx_set_peer(hrs_ctx* ctx, hrs_ctx* peer) {
 
 extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
     if (!ctx) return HRS_OK;
-    hipSetDevice(ctx->device);
-    hipDeviceSynchronize();
+    // teardown: nothing useful can be done about an error here
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
     if (ctx->scan_done) (void)hipEventDestroy(ctx->scan_done);
-    if (ctx->ws_partial.ptr) hipFree(ctx->ws_partial.ptr);
-    if (ctx->ws_mfma.ptr) hipFree(ctx->ws_mfma.ptr);
-    if (ctx->ws_keys.ptr) hipFree(ctx->ws_keys.ptr);
-    if (ctx->stats_dev) hipFree(ctx->stats_dev);
+    if (ctx->ws_partial.ptr) (void)hipFree(ctx->ws_partial.ptr);
+    if (ctx->ws_mfma.ptr) (void)hipFree(ctx->ws_mfma.ptr);
+    if (ctx->ws_keys.ptr) (void)hipFree(ctx->ws_keys.ptr);
+    if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
     for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);
     delete ctx;
@@ -157,8 +158,8 @@ extern "C" int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, 
 
 extern "C" int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* c) {
     if (!c) return HRS_OK;
-    if (ctx) hipSetDevice(ctx->device);
-    hipDeviceSynchronize();
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
     hrs_free_shadow(c);
     delete c;
     return HRS_OK;
