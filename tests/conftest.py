@@ -27,3 +27,10 @@ def corpus_texts():
     d = os.path.join(GOLDEN, "context", "infrastructure")
     names = ["README.md", "automation-guide.md", "bash-linux-reference.md", "windows-powershell-reference.md"]
     return {n: open(os.path.join(d, n), encoding="utf-8", errors="ignore").read() for n in names}
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    import pathlib
+
+    return pathlib.Path(GOLDEN)

@@ -59,3 +59,15 @@ def test_oracle_matches_transformers_bert():
     assert float((got * want).sum(1).min()) > 0.999999
     # the embeddings of different inputs differ (the random network is not degenerate)
     assert float((got[0] * got[1]).sum()) < 0.999
+
+
+def test_oracle_matches_committed_transformers_goldens(golden_dir):
+    """tests/golden/encoder_goldens.npz was produced by transformers.BertModel (make_encoder_goldens.py)."""
+    g = np.load(golden_dir / "encoder_goldens.npz")
+    cfg = W.EncoderConfig()
+    w = W.generate(cfg, seed=int(g["seed"]))
+    got, hidden = EO.forward(w, g["ids"], g["lens"], cfg, return_hidden=True)
+    assert np.abs(got.numpy() - g["embeddings"]).max() < 2e-6
+    assert len(hidden) == cfg.layers + 1  # embedding output, then every layer
+    assert np.abs(hidden[1][:, :4, :16].numpy() - g["hidden_layer0"]).max() < 2e-5
+    assert np.abs(hidden[-1][:, :4, :16].numpy() - g["hidden_final"]).max() < 5e-5

@@ -90,3 +90,15 @@ def test_full_batch_is_batch_invariant(setup):
     got = full[sel].cpu().numpy()
     cos = (want * got).sum(1) / (np.linalg.norm(want, axis=1) * np.linalg.norm(got, axis=1))
     assert cos.min() >= COS_TOL, cos
+
+
+def test_encoder_matches_transformers_goldens(setup, golden_dir):
+    """Against embeddings a transformers.BertModel produced from the same generated weights
+    (tests/golden/make_encoder_goldens.py); tolerance: cosine >= 0.999."""
+    eng, enc, w, cfg = setup
+    g = np.load(golden_dir / "encoder_goldens.npz")
+    assert int(g["seed"]) == 2026
+    got = enc.encode_ids(torch.from_numpy(g["ids"]).cuda(), torch.from_numpy(g["lens"]).cuda()).cpu().numpy()
+    want = g["embeddings"]
+    cos = (want * got).sum(1) / (np.linalg.norm(want, axis=1) * np.linalg.norm(got, axis=1))
+    assert cos.min() >= COS_TOL, cos
