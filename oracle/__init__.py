@@ -23,6 +23,7 @@ Pinning status
 * ``encoder_oracle`` -- sentence-transformers / MiniLM weights are absent and
   cannot be fetched: **parity unpinned** against the real model.  The oracle is
   an fp32 restatement of the BERT/MiniLM-L6 forward with generator-seeded
-  weights, cross-checked in the build container against a config-constructed
-  ``transformers.BertModel`` holding the same weights.
+  weights, checked against a config-constructed ``transformers.BertModel``
+  holding the same weights, live and through the committed vectors that model
+  produced (``tests/golden/encoder_goldens.npz``).
 """
