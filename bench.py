@@ -275,7 +275,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = B * args.steps / elapsed * (world if layout == "replica" else 1)
-        used_mfma = args.mode == "mfma" or (args.mode == "auto" and B > 4 and n_local >= 65536)
+        used_mfma = args.mode == "mfma" or (args.mode == "auto" and n_local >= 65536 and (B > 4 or (shadow == "i8" and n_local * D >= 8e8)))
         kern_avg_ms = kern_ms / max(launches, 1)
         if used_mfma:
             flops = 2.0 * B * n_local * D  # algorithmic: 2*B*N*D per pass of this GPU's shard

@@ -227,7 +227,10 @@ extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, i
     else if (mode == HRS_MODE_MFMA)
         use_mfma = true;
     else
-        use_mfma = B > 4 && c->N >= 65536;
+        // Large batches: the matrix cores.  Up to four queries: one pass of the fp64 streaming scan over the
+        // fp32 rows -- unless the corpus is so large that streaming the int8 shadow (a quarter of the bytes)
+        // plus the fixed cost of the candidate machinery (~0.25 ms) is faster: measured cross-over ~1.2M x 384.
+        use_mfma = c->N >= 65536 && (B > 4 || (c->kind == HRS_SHADOW_I8 && (double)c->N * c->D >= 8e8));
     if (use_mfma && (c->N < 4096 || c->N < (int64_t)k * 64)) use_mfma = false;
 
     int rc = use_mfma ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st)

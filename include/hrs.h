@@ -46,9 +46,10 @@ enum hrs_status {
  * (scripts/chromadb_helper.py:82-86). */
 enum hrs_space { HRS_SPACE_L2 = 0, HRS_SPACE_COSINE = 1, HRS_SPACE_IP = 2 };
 
-/* How hrs_score_topk scores. AUTO picks EXACT for small batches / small or masked corpora and
- * MFMA otherwise.  Both return identical results (MFMA re-scores its candidates exactly and
- * falls back to EXACT for any query it cannot prove). */
+/* How hrs_score_topk scores. AUTO picks EXACT for small corpora and for batches of up to four queries
+ * (except over an int8 shadow of more than ~2M x 384 elements, which streams faster) and MFMA
+ * otherwise.  Both return identical results (MFMA re-scores its candidates exactly and falls back
+ * to EXACT for any query it cannot prove). */
 enum hrs_score_mode { HRS_MODE_AUTO = 0, HRS_MODE_EXACT = 1, HRS_MODE_MFMA = 2 };
 
 /* The reduced-precision copy of the corpus that the MFMA scan streams.  I8: int8 with one fp32 scale
