@@ -97,12 +97,14 @@ def cpu_baseline(corpus_matrix, terms, queries, q_terms, q_offs, n_keep, n_total
     }
 
 
-def bench_embed(eng, batches=4, B=1024, S=256):
-    """BASELINE config 3 shape: MiniLM-L6 embedding of full-length (256-token) synthetic chunks, batch 1024."""
+def bench_embed(eng, batches=4, B=1024, S=256, cpu_chunks=32):
+    """BASELINE config 3 shape: MiniLM-L6 embedding of full-length (256-token) synthetic chunks, batch 1024;
+    beside it the fp32 oracle (torch on the host cores, sentence-transformers' default batch of 32)."""
     from hybrid_rag_system_amd import weights as W
 
     cfg = W.EncoderConfig()
-    enc = eng.encoder(W.generate(cfg, 2026), cfg)
+    wts = W.generate(cfg, 2026)
+    enc = eng.encoder(wts, cfg)
     g = torch.Generator(device="cpu").manual_seed(3)
     ids = torch.randint(1000, 30000, (B, S), generator=g, dtype=torch.int32)
     ids[:, 0], ids[:, -1] = 101, 102
@@ -118,8 +120,19 @@ def bench_embed(eng, batches=4, B=1024, S=256):
     dt = (time.perf_counter() - t0) / batches
     enc.close()
     flops = 6.040e9 * B  # 23 592 960 flop per token x 256 tokens
-    return {"chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "tflops": flops / dt / 1e12, "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS["bf16"],
-            "config": f"MiniLM-L6 geometry, generated weights, batch {B} x {S} tokens, bf16 MFMA"}
+    out = {"chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "tflops": flops / dt / 1e12, "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS["bf16"],
+           "config": f"MiniLM-L6 geometry, generated weights, batch {B} x {S} tokens, bf16 MFMA"}
+    if cpu_chunks:
+        from oracle import encoder_oracle as EO  # the checker, timed as the CPU baseline of this extra
+
+        hid, hl = ids[:cpu_chunks].cpu().numpy(), lens[:cpu_chunks].cpu().numpy()
+        EO.forward(wts, hid[:4], hl[:4], cfg)
+        t0 = time.perf_counter()
+        EO.forward(wts, hid, hl, cfg)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": cpu_chunks / cdt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/encoder_oracle.py (fp32 torch) on {cpu_chunks} chunks x {S} tokens in {cdt:.2f}s"}
+    return out
 
 
 def bench_scan(eng, corpus, queries, k=10):
@@ -325,7 +338,7 @@ def main():
             "max_candidates": stats["max_candidates"],
         }
         if world == 1 and not args.no_extras:
-            line["extras"] = {"embed": bench_embed(eng), "exact_scan": bench_scan(eng, corpus, queries)}
+            line["extras"] = {"embed": bench_embed(eng, cpu_chunks=0 if args.no_cpu_baseline else 32), "exact_scan": bench_scan(eng, corpus, queries)}
             line["extras"].update(bench_other_configs(eng))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(matrix, terms, queries, q_terms, q_offs, n_keep, n_total, args.cpu_sample_rows, args.cpu_sample_queries)
