@@ -115,12 +115,19 @@ extern "C" int hrs_ctx_set_peer(hrs_ctx* ctx, hrs_ctx* peer) {
     HRS_REQUIRE(!peer || peer->device == ctx->device, "hrs_ctx_set_peer: contexts on different devices");
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     if (!ctx->scan_done) HRS_CHECK_HIP(hipEventCreateWithFlags(&ctx->scan_done, hipEventDisableTiming));
+    if (ctx->peer) ctx->peer->waiter = nullptr;
     ctx->peer = peer;
+    if (peer) {
+        if (peer->waiter && peer->waiter != ctx) peer->waiter->peer = nullptr;  // one waiter per context
+        peer->waiter = ctx;
+    }
     return HRS_OK;
 }
 
 extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
     if (!ctx) return HRS_OK;
+    if (ctx->waiter) ctx->waiter->peer = nullptr;  // nobody may wait on a destroyed context's event
+    if (ctx->peer) ctx->peer->waiter = nullptr;
     // teardown: nothing useful can be done about an error here
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();

@@ -50,6 +50,7 @@ struct hrs_ctx {
     // two contexts that serve alternate batches on two streams: each scan waits for the peer's last scan,
     // so scans never share the matrix pipes with each other, only with the peer's re-score tail
     hrs_ctx* peer = nullptr;
+    hrs_ctx* waiter = nullptr;  // the context whose `peer` this one is (cleared when either is destroyed)
     hipEvent_t scan_done = nullptr;
     bool scan_recorded = false;
     // optional kernel timing (hrs_profile_*): event pairs around the dominant scan kernel
