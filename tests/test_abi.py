@@ -43,3 +43,16 @@ def test_engine_fails_loudly_without_gpu():
 
     with pytest.raises(_native.HrsError):
         Engine(0)
+
+
+def test_header_compiles_as_c(tmp_path):
+    """include/hrs.h is a C header: gcc -std=c11 -fsyntax-only on a translation unit that includes it."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "hrs.h"\nint main(void) { return hrs_version() < 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
