@@ -58,7 +58,11 @@ def _uniform(seed, tensor_index, n):
 
 
 def generate(cfg=EncoderConfig(), seed=2026):
-    """Deterministic weights: matrices ~ U(-a, a) with BERT-like scale, LayerNorm gains near 1."""
+    """Deterministic weights, uniform with per-kind scales chosen so that the random network behaves like an
+    embedding model rather than collapsing every input onto one direction: word embeddings dominate the
+    position / type embeddings and the biases (the part common to all inputs), and the sub-layers add to the
+    residual stream without swamping it.  Unrelated random inputs then embed at cosine ~0.2 (with equal
+    scales everywhere it is ~0.99 and bf16-vs-fp32 rank comparisons are meaningless)."""
     out = {}
     for t, (name, shape) in enumerate(tensor_specs(cfg)):
         n = int(np.prod(shape))
@@ -67,11 +71,13 @@ def generate(cfg=EncoderConfig(), seed=2026):
         if base.endswith("_g"):
             w = 1.0 + 0.1 * u
         elif base.endswith("_b"):
-            w = 0.05 * u
-        elif base in ("word_emb", "pos_emb", "type_emb"):
-            w = 0.08 * u
+            w = 0.01 * u
+        elif base == "word_emb":
+            w = 0.5 * u
+        elif base in ("pos_emb", "type_emb"):
+            w = 0.02 * u
         else:
-            w = u * np.float32(1.2 / np.sqrt(shape[1]))  # var = 0.48 / fan_in: keeps activations O(1)
+            w = u * np.float32(0.6 / np.sqrt(shape[1]))  # var = 0.12 / fan_in
         out[name] = np.ascontiguousarray(w.astype(np.float32))
     return out
 

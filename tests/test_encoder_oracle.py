@@ -27,7 +27,7 @@ def test_generator_is_deterministic_and_shaped():
     assert all(w[n].shape == s and w[n].dtype == np.float32 for n, s in specs)
     w2 = W.generate(cfg, seed=7)
     assert all(np.array_equal(w[n], w2[n]) for n, _ in specs)
-    assert abs(float(w["l0.q_w"].std()) - 1.2 / np.sqrt(384) / np.sqrt(3)) < 1e-3
+    assert abs(float(w["l0.q_w"].std()) - 0.6 / np.sqrt(384) / np.sqrt(3)) < 1e-3
     assert float(w["word_emb"][:4].sum()) == float(W.generate(cfg, seed=7)["word_emb"][:4].sum())
 
 
