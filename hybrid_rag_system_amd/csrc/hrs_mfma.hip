@@ -58,6 +58,7 @@ struct MfmaArgs {
     int64_t tiles;         // ceil(N / TR)
     int64_t row_offset;
     int nqg;               // query groups of 256 (1, 2 or 4); nslices = 256 / nqg
+    int nq;                // queries of this chunk; waves whose queries are all padding only feed the LDS ring
     int ss;                // sampling stride of the sampled passes (tiles)
     const float* lad_inv;  // ladder pass: per query 16 / (largest sampled score - tau)
     int* hist;             // ladder pass: [Bpad][16] sampled scores above tau, by sixteenth of that range
@@ -195,6 +196,16 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 1) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0;
+        if (q0 >= a.nq) {
+            // padding queries only (a small batch): this wave keeps its share of the LDS-DMA ring going and
+            // meets the same barriers, and leaves the matrix cores to the waves that hold queries
+            for (int64_t n = 0; n + 1 < count; ++n) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 2) * IPW) : "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(n + HRS_SCAN_NBUF, buf);
+                buf = buf + 1 == HRS_SCAN_NBUF ? 0 : buf + 1;
+            }
+        } else {
         lds_cptr tb[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)bc[c];
@@ -320,6 +331,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 }
             }
         }
+        }  // waves with queries
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (MAXIMA) {
@@ -1086,6 +1098,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.tiles = tiles;
         a.row_offset = c->row_offset;
         a.nqg = nqg;
+        a.nq = bc;
         const int64_t min_len = tiles / nslices;  // shortest slice, in tiles
         int ss = (int)(min_len / 8);
         if (ss > 32) ss = 32;

@@ -16,14 +16,23 @@ def run(eng, seed, cases, verbose=True):
       k = int(rng.choice([1, 3, 10, 20, 64, 128]))
       if n < k * 64: k = 10
       space = str(rng.choice(["l2", "cosine", "ip"]))
-      kind = rng.integers(0, 4)
+      kind = rng.integers(0, 7)
       C = rng.standard_normal((n, d)).astype(np.float32)
       if kind == 0: C /= np.linalg.norm(C, axis=1, keepdims=True)
       elif kind == 1: C *= rng.uniform(0.01, 10, (n, 1)).astype(np.float32)
       elif kind == 2: C = np.round(C * 2).astype(np.float32) / 2      # many exact ties
-      else: C[rng.integers(0, n, n // 10)] = C[0]                      # duplicates
+      elif kind == 3: C[rng.integers(0, n, n // 10)] = C[0]                # duplicates
+      elif kind == 4:                                                  # tight clusters: near-ties by the thousand
+          cen = rng.standard_normal((int(rng.choice([2, 8, 50])), d)).astype(np.float32)
+          C = (cen[rng.integers(0, len(cen), n)] + np.float32(rng.choice([1e-3, 0.05, 0.3])) * C).astype(np.float32)
+      elif kind == 5:                                                  # zero rows, and a zero query below
+          C[rng.integers(0, n, n // 20)] = 0
+      else:                                                            # a few dominant components
+          C[:, rng.integers(0, d, max(1, d // 16))] *= np.float32(100)
       Q = rng.standard_normal((b, d)).astype(np.float32)
       if rng.random() < 0.5: Q[0] = C[rng.integers(0, n)]
+      if kind == 5: Q[-1] = 0
+      if kind == 4: Q[: max(1, b // 2)] = C[rng.integers(0, n, max(1, b // 2))]
       use_mask = rng.random() < 0.3
       mask = (rng.random(n) < rng.choice([0.9, 0.3, 0.01])).astype(np.uint8) if use_mask else None
       want = so.topk_keys(Q, C, k, space, mask=mask)
