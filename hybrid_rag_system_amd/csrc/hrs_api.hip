@@ -233,11 +233,16 @@ extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, i
         use_mfma = false;
     else if (mode == HRS_MODE_MFMA)
         use_mfma = true;
-    else
+    else {
         // Large batches: the matrix cores.  Up to four queries: one pass of the fp64 streaming scan over the
-        // fp32 rows -- unless the corpus is so large that streaming the int8 shadow (a quarter of the bytes)
-        // plus the fixed cost of the candidate machinery (~0.25 ms) is faster: measured cross-over ~1.2M x 384.
-        use_mfma = c->N >= 65536 && (B > 4 || (c->kind == HRS_SHADOW_I8 && (double)c->N * c->D >= 8e8));
+        // fp32 rows -- unless streaming the shadow (a quarter or half of the bytes) plus the fixed cost of the
+        // candidate machinery (~0.16 ms) is faster.  Measured cross-overs in elements of the corpus:
+        // int8 shadow 3e8 (one or two queries) and 1.5e8 (three or four); bf16 shadow 6e8 and 2e8.
+        const double elems = (double)c->N * c->D;
+        const bool i8 = c->kind == HRS_SHADOW_I8;
+        const double cross = B <= 2 ? (i8 ? 3e8 : 6e8) : (i8 ? 1.5e8 : 2e8);
+        use_mfma = c->N >= 65536 && (B > 4 || elems >= cross);
+    }
     if (use_mfma && (c->N < 4096 || c->N < (int64_t)k * 64)) use_mfma = false;
 
     int rc = use_mfma ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st)

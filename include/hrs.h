@@ -46,9 +46,9 @@ enum hrs_status {
  * (scripts/chromadb_helper.py:82-86). */
 enum hrs_space { HRS_SPACE_L2 = 0, HRS_SPACE_COSINE = 1, HRS_SPACE_IP = 2 };
 
-/* How hrs_score_topk scores. AUTO picks EXACT for small corpora and for batches of up to four queries
- * (except over an int8 shadow of more than ~2M x 384 elements, which streams faster) and MFMA
- * otherwise.  Both return identical results (MFMA re-scores its candidates exactly and falls back
+/* How hrs_score_topk scores. AUTO picks EXACT for corpora under 65536 rows and, for batches of up to
+ * four queries, under the size where streaming the shadow becomes faster than streaming the fp32 rows
+ * (measured: 1.5e8 - 3e8 elements over an int8 shadow, 2e8 - 6e8 over a bf16 one), and MFMA otherwise.  Both return identical results (MFMA re-scores its candidates exactly and falls back
  * to EXACT for any query it cannot prove). */
 enum hrs_score_mode { HRS_MODE_AUTO = 0, HRS_MODE_EXACT = 1, HRS_MODE_MFMA = 2 };
 

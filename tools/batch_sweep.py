@@ -16,7 +16,7 @@ print("batch  path   ms/batch   queries/s   fp32-algorithmic GB/s   streamed GB/
 print("(the matrix-core path streams the int8 shadow, a quarter of the fp32 bytes: its HBM fraction is that of the streamed bytes)")
 for B in (1, 2, 4, 8, 32, 128, 256, 512, 1024):
     q = eng.synth_rows(4321, 0, B, D)
-    for mode in (("exact",) if B <= 4 else ("mfma",)) + (("exact",) if B == 8 else ()):
+    for mode in (("exact", "mfma") if B <= 4 else ("mfma",)) + (("exact",) if B == 8 else ()):
         eng.score_topk(c, q, K, mode=mode); torch.cuda.synchronize()
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         reps = 5
