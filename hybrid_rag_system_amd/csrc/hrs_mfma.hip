@@ -42,9 +42,9 @@ template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 #ifndef HRS_SCAN_PF
 #define HRS_SCAN_PF 4
 #endif
-#ifndef HRS_SCAN_NBUF
-#define HRS_SCAN_NBUF 3
-#endif
+// Depth of the LDS ring of corpus tiles (one less is in flight): as deep as 128 KB allows, at most 5.  A
+// small batch is bound by the bytes in flight per CU (at depth 384, int8: two 24 KB tiles sustain 5.3 TB/s, four 5.5 TB/s).
+constexpr int scan_nbuf(int tile_bytes) { return tile_bytes * 5 <= 128 * 1024 ? 5 : (tile_bytes * 4 <= 128 * 1024 ? 4 : 3); }
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     constexpr int NW = 8;                     // waves per workgroup (256 * QT queries)
     constexpr int RB = KS * 32;               // row bytes
     constexpr int TILE_BYTES = TR * RB;
+    constexpr int NBUF = scan_nbuf(TILE_BYTES);
     constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
     constexpr int NSUB = TR / 32;
     constexpr int PPR = 2 * KS;               // 16-byte pieces per row
@@ -192,18 +193,18 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         };
         if (I8) scale_load(tile_at(0));
 #pragma unroll
-        for (int g = 0; g < HRS_SCAN_NBUF; ++g) issue(g, g);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 1) * IPW) : "memory");
+        for (int g = 0; g < NBUF; ++g) issue(g, g);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0;
         if (q0 >= a.nq) {
             // padding queries only (a small batch): this wave keeps its share of the LDS-DMA ring going and
             // meets the same barriers, and leaves the matrix cores to the waves that hold queries
             for (int64_t n = 0; n + 1 < count; ++n) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 2) * IPW) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
                 __builtin_amdgcn_s_barrier();
-                issue(n + HRS_SCAN_NBUF, buf);
-                buf = buf + 1 == HRS_SCAN_NBUF ? 0 : buf + 1;
+                issue(n + NBUF, buf);
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
             }
         } else {
         lds_cptr tb[NB];
@@ -257,10 +258,10 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
                 } else if (n + 1 < count) {
                     // tile boundary: tile n+1 has landed once at most one younger tile is outstanding
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HRS_SCAN_NBUF - 2) * IPW) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
                     __builtin_amdgcn_s_barrier();
-                    issue(n + HRS_SCAN_NBUF, buf);  // tile n's buffer is free: every wave has consumed its fragments
-                    buf = buf + 1 == HRS_SCAN_NBUF ? 0 : buf + 1;
+                    issue(n + NBUF, buf);  // tile n's buffer is free: every wave has consumed its fragments
+                    buf = buf + 1 == NBUF ? 0 : buf + 1;
 #pragma unroll
                     for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
 #pragma unroll
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
 
 template <int KS, int TR, bool I8, int QT>
 static int launch_scan_qt(const MfmaArgs& a, int mode, hipStream_t st) {
-    const size_t lds = (size_t)HRS_SCAN_NBUF * TR * KS * 32;
+    const size_t lds = (size_t)scan_nbuf(TR * KS * 32) * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 0, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
