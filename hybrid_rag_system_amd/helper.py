@@ -10,8 +10,10 @@ with the embedding model and the vector store replaced by the MI355X engine in t
 Configuration keeps the reference's environment names (CHROMADB_COLLECTION, EMBEDDING_MODEL,
 CHUNK_SIZE, CHUNK_OVERLAP; CHROMADB_HOST / CHROMADB_PORT are accepted and unused: there is no
 server).  HRS_DATA_DIR names the directory that persists collections between invocations,
-HRS_MODEL_DIR a local model directory, HRS_DEVICE the GPU.  Additions beside the reference surface:
-`embed`, `query_batch`, `hybrid_query_batch`.
+HRS_MODEL_DIR a local model directory, HRS_DEVICE the GPU.  With HRS_SERVER set to the Unix socket of a
+resident engine (`python -m hybrid_rag_system_amd.server`), collections are reached through it, as the
+reference reaches its Chroma server, and this process loads neither torch nor the library.  Additions
+beside the reference surface: `embed`, `query_batch`, `hybrid_query_batch`.
 """
 import argparse
 import json
@@ -54,12 +56,23 @@ def get_embedding_function():
     return _embedding_function
 
 
+def _server_address():
+    return os.getenv("HRS_SERVER") or None
+
+
 def get_client():
+    """scripts/chromadb_helper.py:74-76: the in-process store, or the resident engine named by HRS_SERVER
+    (an unreachable server raises, as an unreachable Chroma server does in the reference)."""
     global _client
     if _client is None:
-        from .store import Client
+        if _server_address():
+            from .remote import RemoteClient
 
-        _client = Client(DATA_DIR)
+            _client = RemoteClient(_server_address())
+        else:
+            from .store import Client
+
+            _client = Client(DATA_DIR)
     return _client
 
 
@@ -67,7 +80,7 @@ def get_collection(name=None):
     """scripts/chromadb_helper.py:79-86."""
     return get_client().get_or_create_collection(
         name=name or DEFAULT_COLLECTION,
-        embedding_function=get_embedding_function(),
+        embedding_function=None if _server_address() else get_embedding_function(),  # the server embeds
         metadata={"description": "Infrastructure and homelab documentation"},
     )
 
@@ -126,7 +139,9 @@ def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.
 
 # ---- batched additions (not in the reference: it has one query per process) -------------------------
 def embed(texts):
-    """List[str] -> fp32 [n, 384] CUDA tensor of unit rows."""
+    """List[str] -> fp32 [n, 384] CUDA tensor of unit rows (through a resident engine: nested lists)."""
+    if _server_address():
+        return get_client().embed(texts)
     return get_embedding_function().embed_tensor(list(texts))
 
 

@@ -24,3 +24,12 @@ with tempfile.TemporaryDirectory() as d:
     t0 = time.time()
     out = helper.hybrid_query_batch(["proxmox backup schedule", "docker network bridge"] * 64, n_results=5, collection_name="bench")
     print(f"128 hybrid queries: {(time.time()-t0)*1e3:.1f} ms")
+    # one query at a time, as the reference's CLI and bridge issue them (in-process: without the interpreter start)
+    for name, fn in (("embed", lambda: helper.embed(["proxmox backup schedule"])),
+                     ("query", lambda: helper.query("proxmox backup schedule", 5, "bench")),
+                     ("hybrid_query", lambda: helper.hybrid_query("proxmox backup schedule", 5, "bench"))):
+        fn(); torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(50): fn()
+        torch.cuda.synchronize()
+        print(f"single {name}: {(time.time()-t0)/50*1e3:.2f} ms")
