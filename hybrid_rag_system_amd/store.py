@@ -70,8 +70,13 @@ class HrsEmbeddingFunction:
         return self.embed_tensor(list(input)).cpu().numpy().tolist()
 
 
+_COMPARE = {"$gt": lambda v, a: v > a, "$gte": lambda v, a: v >= a, "$lt": lambda v, a: v < a, "$lte": lambda v, a: v <= a}
+
+
 def _match(meta, where):
-    """ChromaDB `where` subset: {"k": v}, {"k": {"$eq"|"$ne"|"$in"|"$nin": ...}}, {"$and": [...]}, {"$or": [...]}."""
+    """ChromaDB `where` subset: {"k": v}, {"k": {"$eq"|"$ne"|"$in"|"$nin"|"$gt"|"$gte"|"$lt"|"$lte"|"$contains": ...}},
+    {"$and": [...]}, {"$or": [...]} -- the forms the reference's callers build (scripts/chromadb_helper.py:265-266,
+    scripts/hybrid-rag.py:358-370, scripts/improved-router.py:463-477).  A missing key matches only `$ne` / `$nin`."""
     for key, cond in where.items():
         if key == "$and":
             if not all(_match(meta, w) for w in cond):
@@ -90,6 +95,10 @@ def _match(meta, where):
                     ok = v in arg
                 elif op == "$nin":
                     ok = v not in arg
+                elif op in _COMPARE:
+                    ok = isinstance(v, (int, float)) and not isinstance(v, bool) and isinstance(arg, (int, float)) and _COMPARE[op](v, arg)
+                elif op == "$contains":  # substring of a string value, or membership in a list value
+                    ok = isinstance(v, (str, list, tuple)) and arg in v
                 else:
                     raise ValueError(f"unsupported where operator {op}")
                 if not ok:

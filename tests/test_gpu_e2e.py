@@ -97,6 +97,25 @@ def test_persistence_where_filter_and_bridge(helper):
     assert len(res["metadatas"][0]) == min(5, n_sys) and all(m["system"] == sysname for m in res["metadatas"][0])
     none = helper.query("container restart", 5, "cfg1", {"system": "no-such-system"})
     assert none["ids"] == [[]]
+    # the compound filters other callers of the reference build (scripts/hybrid-rag.py:358-370,
+    # scripts/improved-router.py:463-477): rows and distances equal the oracle's over the kept rows
+    from hybrid_rag_system_amd.store import _match
+
+    word = "docker"
+    for where in (
+        {"$or": [{"system": s} for s in systems[:2]]},
+        {"$and": [{"system": sysname}, {"source": {"$contains": ".md"}}]},
+        {"title": {"$contains": word}},
+        {"chunk_index": {"$gte": 2, "$lt": 6}},
+    ):
+        keep = np.array([_match(m, where) for m in col.metadatas], np.uint8)
+        got = helper.query("container restart", 7, "cfg1", where)
+        qe = helper.embed(["container restart"]).cpu().numpy()
+        wd, wr = so.topk(qe, col._emb, 7, "l2", mask=keep)
+        want_rows = [int(r) for r in wr[0] if r >= 0]
+        assert got["ids"][0] == [col.ids[r] for r in want_rows], where
+        assert got["distances"][0] == [float(x) for x in wd[0][: len(want_rows)]]
+        assert len(want_rows) == min(7, int(keep.sum()))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bridge.main(["query", QUERIES[0], "--hybrid", "--n-results", "3", "--collection", "cfg1"])

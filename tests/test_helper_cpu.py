@@ -205,3 +205,20 @@ def test_clean_text_equals_the_regex_form():
         ch = chr(cp)
         for t in (f"a{ch}b", f"{ch}a {ch}{ch} b{ch}", f"\x00{ch} a", ch):
             assert clean_text(t) == ws.sub(" ", t).replace("\x00", "").strip(), hex(cp)
+
+
+def test_where_forms_of_the_reference_callers():
+    """scripts/chromadb_helper.py:265-266, scripts/hybrid-rag.py:358-370, scripts/improved-router.py:463-477."""
+    from hybrid_rag_system_amd.store import _match
+
+    m = {"system": "unraid", "topics": "docker,networking,backup", "chunk_index": 3}
+    assert _match(m, {"system": "unraid"}) and not _match(m, {"system": "proxmox"}) and not _match(None, {"system": "unraid"})
+    assert _match(m, {"$and": [{"system": "unraid"}, {"topics": {"$contains": "networking"}}]})
+    assert not _match(m, {"$and": [{"system": "unraid"}, {"topics": {"$contains": "kubernetes"}}]})
+    assert _match(m, {"topics": {"$contains": "backup"}}) and not _match({"system": "x"}, {"topics": {"$contains": "backup"}})
+    assert _match(m, {"$or": [{"system": "proxmox"}, {"system": "unraid"}]}) and not _match(m, {"$or": [{"system": "proxmox"}, {"system": "windows"}]})
+    assert _match(m, {"system": {"$in": ["unraid", "docker"]}}) and _match(m, {"system": {"$nin": ["docker"]}}) and _match(m, {"system": {"$ne": "docker"}})
+    assert _match(m, {"chunk_index": {"$gte": 3, "$lt": 4}}) and not _match(m, {"chunk_index": {"$gt": 3}}) and not _match(m, {"system": {"$gt": 1}})
+    assert _match({}, {"system": {"$ne": "x"}}) and not _match({}, {"system": {"$eq": "x"}})
+    with pytest.raises(ValueError, match="unsupported where operator"):
+        _match(m, {"system": {"$regex": "u.*"}})
