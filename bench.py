@@ -212,7 +212,10 @@ def main():
     # one device); never the measured configuration
     rehearsal = os.environ.get("HRS_BENCH_REHEARSAL") == "1"
     if rehearsal:
+        import faulthandler
+
         local_rank = 0
+        faulthandler.dump_traceback_later(120, exit=True)  # a rehearsal that stops says where
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -288,7 +291,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = B * args.steps / elapsed * (world if layout == "replica" else 1)
-        used_mfma = args.mode == "mfma" or (args.mode == "auto" and n_local >= 65536 and (B > 4 or (shadow == "i8" and n_local * D >= 8e8)))
+        cross = (3e8 if B <= 2 else 1.5e8) if shadow == "i8" else (6e8 if B <= 2 else 2e8)  # the library's HRS_MODE_AUTO rule
+        used_mfma = args.mode == "mfma" or (args.mode == "auto" and n_local >= 65536 and (B > 4 or n_local * D >= cross))
         kern_avg_ms = kern_ms / max(launches, 1)
         if used_mfma:
             flops = 2.0 * B * n_local * D  # algorithmic: 2*B*N*D per pass of this GPU's shard

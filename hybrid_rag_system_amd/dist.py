@@ -26,8 +26,15 @@ def allgather_candidates(keys, counts, group=None):
     world = dist.get_world_size(group)
     payload = pack_candidates(keys, counts)
     # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [G, B, c, 2]
-    flat = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
-    dist.all_gather_into_tensor(flat, payload, group=group)
+    if payload.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo (rehearsals and CPU tests only) moves device tensors at a crawl: stage through the host
+        host = payload.cpu()
+        flat_host = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(flat_host, host, group=group)
+        flat = flat_host.to(payload.device)
+    else:
+        flat = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+        dist.all_gather_into_tensor(flat, payload, group=group)
     out = flat.view((world,) + tuple(payload.shape))
     return out[..., 0].contiguous(), out[..., 1].to(torch.int32).contiguous()
 
