@@ -658,11 +658,25 @@ int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st) {
     return HRS_OK;
 }
 
+// The few control words a call starts from zero (queue lengths, statistics) are cleared by the first
+// kernel of the call instead of by memset nodes of their own: three launches less per call.
+struct ZeroList {
+    int32_t* p[3];
+    int n[3];  // 32-bit words each (<= 64)
+};
+__device__ __forceinline__ void zero_words(const ZeroList& z) {
+    if (blockIdx.x == 0 && threadIdx.x < 192) {
+        const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+        if (z.p[w] && t < z.n[w]) z.p[w][t] = 0;
+    }
+}
+
 // Queries fp32 [B, D] -> int8 [Bpad, Dpad] with one scale per query (max |q| / 127); squared norms in
 // fp64, the scale and K_q = e |q_int|_1 + e^2 D of the error bound.  One wave per query.
 __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ Q, int B, int D, int Bpad, int Dpad,
                                                       int8_t* __restrict__ qb, double* __restrict__ qn2,
-                                                      float* __restrict__ qscale, float* __restrict__ kq) {
+                                                      float* __restrict__ qscale, float* __restrict__ kq, ZeroList z) {
+    zero_words(z);
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Bpad) return;
@@ -693,7 +707,8 @@ __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ 
 
 // Queries fp32 [B, D] -> bf16 [Bpad, Dpad] (zero padded), squared norms in fp64. One wave per query.
 __global__ __launch_bounds__(256) void k_convert_q(const float* __restrict__ Q, int B, int D, int Bpad, int Dpad,
-                                                   __bf16* __restrict__ qb, double* __restrict__ qn2) {
+                                                   __bf16* __restrict__ qb, double* __restrict__ qn2, ZeroList z) {
+    zero_words(z);
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Bpad) return;
@@ -1071,8 +1086,6 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     char* ws = (char*)ctx->ws_mfma.ptr;
     int32_t* nflag = (int32_t*)(ws + o_ctrl);
     int32_t* qlist = (int32_t*)(ws + o_qlist);
-    HRS_CHECK_HIP(hipMemsetAsync(nflag, 0, 256, st));
-    HRS_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 8 * sizeof(int64_t), st));
 
     const int64_t tiles = (c->N + TR - 1) / TR;
     if (ctx->peer && ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
@@ -1083,13 +1096,22 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         const int qt = (i8 && KS <= 12 && bpad >= 512 && !getenv("HRS_SCAN_QT1")) ? 2 : 1;
         const int nqg = bpad / (wide ? 128 : MF_QPB * qt);
         const int nslices = HRS_NUM_CU / nqg;
+        // cleared by the convert kernel: this chunk's deferred-queue length; for the first chunk also the
+        // fallback-queue length and the call's statistics
+        ZeroList z;
+        z.p[0] = (int32_t*)(ws + o_q2);
+        z.n[0] = 1;
+        z.p[1] = qbase == 0 ? nflag : nullptr;
+        z.n[1] = 64;
+        z.p[2] = qbase == 0 ? (int32_t*)ctx->stats_dev : nullptr;
+        z.n[2] = 16;
         if (i8)
             hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                                bpad, Dpad, (int8_t*)(ws + o_qb), (double*)(ws + o_qn), (float*)(ws + o_qs),
-                               (float*)(ws + o_kq));
+                               (float*)(ws + o_kq), z);
         else
             hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
-                               bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn));
+                               bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn), z);
         MfmaArgs a;
         a.shadow = (const char*)c->shadow;
         a.qb = (const char*)(ws + o_qb);
@@ -1214,7 +1236,6 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.qbase = qbase;
         s.qlist2 = (int32_t*)(ws + o_q2) + 64;
         s.nflag2 = (int32_t*)(ws + o_q2);
-        HRS_CHECK_HIP(hipMemsetAsync(s.nflag2, 0, sizeof(int32_t), st));
         if (space == HRS_SPACE_L2)
             rc = launch_select<HRS_SPACE_L2>(s, bc, st);
         else if (space == HRS_SPACE_COSINE)
