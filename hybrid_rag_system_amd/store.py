@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import weights as W
+from ._native import MAX_K
 from .tokenizer import HashTokenizer, WordPieceTokenizer
 
 _ENGINE = None
@@ -224,12 +225,15 @@ class Collection:
         nq = q.shape[0]
         rows = dist = None
         if self.count() and n_results > 0:
-            k = min(int(n_results), 128)
+            k = min(int(n_results), self.count())
             mask = None
             if where:
                 keep = np.fromiter((_match(m, where) for m in self.metadatas), np.uint8, len(self.metadatas))
                 mask = torch.from_numpy(keep).to(eng.device)
-            d, r = eng.score_topk(self._resident(), q.contiguous(), k, space=self.space, mask=mask)
+            if k <= MAX_K:
+                d, r = eng.score_topk(self._resident(), q.contiguous(), k, space=self.space, mask=mask)
+            else:
+                d, r = self._topk_beyond_max(q.contiguous(), k, mask)
             rows, dist = r.cpu().numpy(), d.cpu().numpy()
         res = {"ids": [], "documents": [] if "documents" in include else None, "metadatas": [] if "metadatas" in include else None, "distances": [] if "distances" in include else None}
         for b in range(nq):
@@ -242,6 +246,29 @@ class Collection:
             if res["distances"] is not None:
                 res["distances"].append([float(dist[b][j]) for j in range(len(rr))])
         return res
+
+    def _topk_beyond_max(self, q, k, mask):
+        """More results than one scan returns (n_results is unbounded in the reference): per query, passes of
+        MAX_K with the rows already returned masked out.  The order is total (distance, then row), so the
+        passes concatenate to the exact top-k."""
+        eng = engine()
+        n = self.count()
+        dist = torch.full((q.shape[0], k), float("inf"), dtype=torch.float32, device=eng.device)
+        rows = torch.full((q.shape[0], k), -1, dtype=torch.int64, device=eng.device)
+        for b in range(q.shape[0]):
+            keep = mask.clone() if mask is not None else torch.ones(n, dtype=torch.uint8, device=eng.device)
+            got = 0
+            while got < k:
+                step = min(MAX_K, k - got)
+                d, r = eng.score_topk(self._resident(), q[b : b + 1], step, space=self.space, mask=keep)
+                found = int((r[0] >= 0).sum())
+                dist[b, got : got + found] = d[0, :found]
+                rows[b, got : got + found] = r[0, :found]
+                got += found
+                if found < step:
+                    break
+                keep[r[0, :found]] = 0
+        return dist, rows
 
     def peek(self, limit=10):
         n = min(limit, self.count())
