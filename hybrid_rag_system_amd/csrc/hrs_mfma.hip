@@ -44,7 +44,14 @@ template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 #endif
 // Depth of the LDS ring of corpus tiles (one less is in flight): as deep as 128 KB allows, at most 5.  A
 // small batch is bound by the bytes in flight per CU (at depth 384, int8: two 24 KB tiles sustain 5.3 TB/s, four 5.5 TB/s).
-constexpr int scan_nbuf(int tile_bytes) { return tile_bytes * 5 <= 128 * 1024 ? 5 : (tile_bytes * 4 <= 128 * 1024 ? 4 : 3); }
+#ifndef HRS_SS_MAX
+#define HRS_SS_MAX 32   // sampled passes: at most one tile in this many
+#define HRS_J_MIN 16    // tau is at least the j-th largest stream maximum
+#endif
+#ifndef HRS_SCAN_RING_BYTES
+#define HRS_SCAN_RING_BYTES (128 * 1024)
+#endif
+constexpr int scan_nbuf(int tile_bytes) { return tile_bytes * 5 <= HRS_SCAN_RING_BYTES ? 5 : (tile_bytes * 4 <= HRS_SCAN_RING_BYTES ? 4 : 3); }
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
@@ -1124,7 +1131,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.nq = bc;
         const int64_t min_len = tiles / nslices;  // shortest slice, in tiles
         int ss = (int)(min_len / 8);
-        if (ss > 32) ss = 32;
+        if (ss > HRS_SS_MAX) ss = HRS_SS_MAX;
         if (ss < 1) ss = 1;
         a.ss = ss;
         a.maxima = (float*)(ws + o_max);
@@ -1138,7 +1145,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         // aim at ~max(384, 6k) rows above tau; expected count ~ ss * M * -ln(1 - j/M)
         int target = 6 * k > 384 ? 6 * k : 384;
         int j = (target + ss - 1) / ss;
-        if (j < 16) j = 16;
+        if (j < HRS_J_MIN) j = HRS_J_MIN;
         if (j > M / 2) j = M / 2;
 
         // sampled maxima -> first tau -> sampled ladder counts -> tau raised where rows come in runs -> scan

@@ -6,13 +6,18 @@ from hybrid_rag_system_amd.engine import Engine
 from oracle import search_oracle as so
 
 
-def run(eng, seed, cases, verbose=True):
+def run(eng, seed, cases, verbose=True, large=False):
   rng = np.random.default_rng(seed)
   bad = 0
   for it in range(cases):
       n = int(rng.choice([4096, 5000, 9999, 33000, 70001, 131072]))
       d = int(rng.choice([4, 8, 60, 64, 100, 128, 132, 256, 384, 388, 512, 516, 768, 1024])) 
       b = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 257, 300]))
+      if large:  # slices of many tiles: the sampled passes really sample (stride > 1)
+          n = int(rng.choice([400_000, 1_000_003, 2_000_000]))
+          d = int(rng.choice([64, 128, 384, 768, 1024]))
+          b = int(rng.choice([1, 4, 5, 33, 64, 130, 300, 600]))
+          while n * d * b > 1.2e11: b = max(1, b // 2)
       k = int(rng.choice([1, 3, 10, 20, 64, 128]))
       if n < k * 64: k = 10
       space = str(rng.choice(["l2", "cosine", "ip"]))
@@ -55,4 +60,4 @@ def run(eng, seed, cases, verbose=True):
 if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    print("mismatches:", run(Engine(0), seed, cases))
+    print("mismatches:", run(Engine(0), seed, cases, large=len(sys.argv) > 3 and sys.argv[3] == "large"))
