@@ -731,22 +731,63 @@ __global__ __launch_bounds__(256) void k_convert_q(const float* __restrict__ Q, 
 
 // tau[q] = j-th largest of the query's M stream maxima -- for rows that score independently about
 // `target` rows exceed it.  Also: the ladder step 16 / (largest maximum - tau) and cleared counters.
+// The j-th largest comes from a radix select over the 32-bit order-preserving keys (four passes of a
+// 256-bin histogram), not from a sort.  Streams without a sample hold -inf and rank last.
 __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxima, int M, int j, float* __restrict__ tau,
                                                   int* __restrict__ cnt, float* __restrict__ lad_inv, int* __restrict__ hist) {
-    __shared__ uint64_t s[HRS_MAX_STREAMS];
-    const int q = blockIdx.x;
-    int n2 = 1;
-    while (n2 < M) n2 <<= 1;
-    for (int t = threadIdx.x; t < n2; t += 256) {
-        // descending by value: key = ~orderable; -inf streams (no sample) sort last
-        s[t] = t < M ? (uint64_t)(~f32_orderable(maxima[(size_t)q * HRS_MAX_STREAMS + t])) : HRS_PAD_KEY;
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t sel[2];  // chosen bin, rank within it
+    __shared__ uint32_t smin[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    constexpr int PER = HRS_MAX_STREAMS / 256;
+    uint32_t key[PER];  // ascending key = descending value
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int t = tid + e * 256;
+        key[e] = t < M ? ~f32_orderable(maxima[(size_t)q * HRS_MAX_STREAMS + t]) : 0xFFFFFFFFu;
+        best = min(best, key[e]);
     }
-    bitonic_sort_u64(s, n2, threadIdx.x, 256);
-    if (threadIdx.x < 16) hist[q * 16 + threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        int jj = j < M ? j : M;
-        const float v = orderable_f32(~(uint32_t)s[jj - 1]);
-        const float top = orderable_f32(~(uint32_t)s[0]);
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+    if ((tid & 63) == 0) smin[tid >> 6] = best;
+    uint32_t prefix = 0, rank = (uint32_t)(j < M ? j : M);  // 1-based rank among the M keys
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        bins[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            if (tid + e * 256 < M && (shift == 24 || (key[e] >> (shift + 8)) == prefix)) atomicAdd(&bins[(key[e] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {  // wave 0: inclusive scan of the 256 bins, four per lane
+            uint32_t c[4], run = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                run += bins[tid * 4 + e];
+                c[e] = run;
+            }
+            uint32_t incl = run;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+                if (tid >= o) incl += v;
+            }
+            const uint32_t before = incl - run;  // keys in the bins of lower lanes
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t lo = before + (e ? c[e - 1] : 0u), hi = before + c[e];
+                if (rank > lo && rank <= hi) {
+                    sel[0] = (uint32_t)(tid * 4 + e);
+                    sel[1] = rank - lo;
+                }
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sel[0];
+        rank = sel[1];
+    }
+    if (tid < 16) hist[q * 16 + tid] = 0;
+    if (tid == 0) {
+        const float v = orderable_f32(~prefix);
+        const float top = orderable_f32(~min(min(smin[0], smin[1]), min(smin[2], smin[3])));
         tau[q] = v;
         cnt[q] = 0;
         lad_inv[q] = (top > v && top - v < 1e30f) ? 16.0f / (top - v) : 0.f;

@@ -57,15 +57,21 @@ class HrsEmbeddingFunction:
     def embed_tensor(self, texts):
         """-> fp32 [len(texts), 384] CUDA tensor."""
         eng = engine()
-        out = torch.empty((len(texts), self.cfg.hidden), dtype=torch.float32, device=eng.device)
+        n = len(texts)
+        if n == 0:
+            return torch.empty((0, self.cfg.hidden), dtype=torch.float32, device=eng.device)
         # length-sorted batches keep the padding small (sentence-transformers sorts by length too)
-        order = sorted(range(len(texts)), key=lambda i: len(texts[i]))
-        for s in range(0, len(order), self.batch_size):
-            idx = order[s : s + self.batch_size]
-            ids, lens = self.tokenizer.encode_batch([texts[i] for i in idx])
-            emb = self.encoder.encode_ids(torch.from_numpy(ids).to(eng.device), torch.from_numpy(lens).to(eng.device))
-            out[torch.tensor(idx, device=eng.device)] = emb
-        return out
+        order = sorted(range(n), key=lambda i: len(texts[i])) if n > 1 else [0]
+        parts = []
+        for s in range(0, n, self.batch_size):
+            ids, lens = self.tokenizer.encode_batch([texts[i] for i in order[s : s + self.batch_size]])
+            parts.append(self.encoder.encode_ids(torch.from_numpy(ids).to(eng.device), torch.from_numpy(lens).to(eng.device)))
+        emb = parts[0] if len(parts) == 1 else torch.cat(parts)
+        if n == 1:
+            return emb
+        back = np.empty(n, np.int64)
+        back[np.asarray(order)] = np.arange(n)  # one gather restores the caller's order
+        return emb[torch.from_numpy(back).to(eng.device)]
 
     def __call__(self, input):
         return self.embed_tensor(list(input)).cpu().numpy().tolist()
