@@ -39,6 +39,34 @@ def allgather_candidates(keys, counts, group=None):
     return out[..., 0].contiguous(), out[..., 1].to(torch.int32).contiguous()
 
 
+def embed_data_parallel(embed_fn, texts, group=None):
+    """Indexing is data-parallel: rank r embeds the contiguous slice of `texts` that shard_bounds gives it
+    (the rows it will own) with `embed_fn(list[str]) -> fp32 [n, D]`, and nothing is exchanged.
+    -> (lo, hi, rows[lo:hi]).  `gather_rows` assembles the full matrix where a caller wants a replica."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(len(texts), world, rank)
+    return lo, hi, embed_fn(list(texts[lo:hi]))
+
+
+def gather_rows(local_rows, n_total, group=None):
+    """All-gather contiguous row shards (sizes from shard_bounds, so they differ by at most one row)
+    -> [n_total, D] on every rank: one collective, shards padded to the longest."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_rows
+    world = dist.get_world_size(group)
+    longest = max(hi - lo for lo, hi in (shard_bounds(n_total, world, r) for r in range(world)))
+    pad = torch.zeros((longest, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+    pad[: local_rows.shape[0]] = local_rows
+    staged = pad.is_cuda and dist.get_backend(group) == "gloo"  # see allgather_candidates
+    src = pad.cpu() if staged else pad
+    flat = torch.empty((world * longest, local_rows.shape[1]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(flat, src, group=group)
+    parts = [flat[r * longest : r * longest + (shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0])] for r in range(world)]
+    out = torch.cat(parts)
+    return out.to(local_rows.device) if staged else out
+
+
 class ShardedHybrid:
     """Hybrid top-n over a row-sharded corpus; every rank returns the same merged result.
     group=False: this rank holds the whole corpus (single GPU, or one replica of several) and no

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from hybrid_rag_system_amd.dist import allgather_candidates, shard_bounds
+from hybrid_rag_system_amd.dist import allgather_candidates, embed_data_parallel, gather_rows, shard_bounds
 from oracle import search_oracle as so
 
 
@@ -37,7 +37,12 @@ def _worker(rank, world, port, ret):
     counts = (keys & np.uint64(7)).astype(np.int32)  # any payload tied to the key
     gk, gc = allgather_candidates(torch.from_numpy(keys.view(np.int64)), torch.from_numpy(counts))
     merged = so.merge(gk.numpy().view(np.uint64))
-    ret[rank] = (merged, gk.numpy().view(np.uint64), gc.numpy())
+    # data-parallel indexing: each rank embeds the rows it owns; a stand-in encoder (the real one needs the GPU)
+    texts = [f"chunk {i}" for i in range(11)]
+    fake = lambda ts: torch.tensor([[float(t.split()[1]), len(t)] for t in ts], dtype=torch.float32).reshape(-1, 2)
+    elo, ehi, mine = embed_data_parallel(fake, texts)
+    full = gather_rows(mine, len(texts))
+    ret[rank] = (merged, gk.numpy().view(np.uint64), gc.numpy(), (elo, ehi), full.numpy())
     dist.destroy_process_group()
 
 
@@ -50,7 +55,9 @@ def test_two_rank_allgather_and_merge():
     Q, C = _inputs()
     want = so.topk_keys(Q, C, 8, "l2")
     for r in range(world):
-        merged, gk, gc = ret[r]
+        merged, gk, gc, bounds, full = ret[r]
+        assert bounds == shard_bounds(11, world, r)
+        assert np.array_equal(full, np.array([[i, len(f"chunk {i}")] for i in range(11)], np.float32))
         assert np.array_equal(merged, want)
         assert gk.shape == (2, 5, 8) and np.array_equal(gc, (gk & np.uint64(7)).astype(np.int32))
     assert np.array_equal(ret[0][1], ret[1][1])
