@@ -16,3 +16,12 @@ def test_random_shapes_match_oracle():
     eng = Engine(0)
     assert fuzz_search.run(eng, seed=11, cases=16, verbose=False) == 0
     eng.close()
+
+
+def test_random_hybrid_steps_match_oracle():
+    import fuzz_hybrid
+    from hybrid_rag_system_amd.engine import Engine
+
+    eng = Engine(0)
+    assert fuzz_hybrid.run(eng, seed=5, cases=10, verbose=False) == 0
+    eng.close()
