@@ -118,10 +118,33 @@ def bench_embed(eng, batches=4, B=1024, S=256, cpu_chunks=32):
         enc.encode_ids(ids, lens)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / batches
+    # the same number of chunks with lengths ~U[32, 256], sorted by length into batches (what the store's
+    # embedding function does), each batch padded to its longest chunk rounded up to 32 tokens
+    gl = torch.Generator(device="cpu").manual_seed(4)
+    rl, _ = torch.sort(torch.randint(32, S + 1, (batches * B,), generator=gl, dtype=torch.int32))
+    ragged = []
+    for b in range(batches):
+        bl = rl[b * B : (b + 1) * B]
+        sb = (int(bl.max()) + 31) // 32 * 32
+        bi = torch.randint(1000, 30000, (B, sb), generator=gl, dtype=torch.int32)
+        bi[:, 0] = 101
+        bi[torch.arange(B), (bl - 1).long()] = 102
+        ragged.append((bi.to(eng.device), bl.to(eng.device)))
+    for bi, bl in ragged:
+        enc.encode_ids(bi, bl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for bi, bl in ragged:
+        enc.encode_ids(bi, bl)
+    torch.cuda.synchronize()
+    rdt = time.perf_counter() - t0
+    real_tokens = int(rl.sum())
     enc.close()
     flops = 6.040e9 * B  # 23 592 960 flop per token x 256 tokens
     out = {"chunks_per_s": B / dt, "ms_per_batch": dt * 1e3, "tflops": flops / dt / 1e12, "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS["bf16"],
-           "config": f"MiniLM-L6 geometry, generated weights, batch {B} x {S} tokens, bf16 MFMA"}
+           "config": f"MiniLM-L6 geometry, generated weights, batch {B} x {S} tokens, bf16 MFMA",
+           "ragged": {"chunks_per_s": batches * B / rdt, "real_tokens_per_s": real_tokens / rdt, "mean_len": real_tokens / (batches * B),
+                      "config": f"{batches * B} chunks, lengths ~U[32,{S}], length-sorted batches of {B}"}}
     if cpu_chunks:
         from oracle import encoder_oracle as EO  # the checker, timed as the CPU baseline of this extra
 
