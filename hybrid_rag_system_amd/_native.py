@@ -29,6 +29,8 @@ EXPORTS = [
     "hrs_corpus_shadow",
     "hrs_corpus_stats",
     "hrs_score_topk",
+    "hrs_score_topk_begin",
+    "hrs_score_topk_finish",
     "hrs_score_stats",
     "hrs_profile_enable",
     "hrs_profile_read",
@@ -82,6 +84,8 @@ def lib():
             "hrs_corpus_shadow": ([vp, vp, i32, vp], i32),
             "hrs_corpus_stats": ([vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)], i32),
             "hrs_score_topk": ([vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], i32),
+            "hrs_score_topk_begin": ([vp, vp, vp, i32, i32, i32, vp, i32, vp], i32),
+            "hrs_score_topk_finish": ([vp, vp, vp, vp, vp], i32),
             "hrs_score_stats": ([vp, vp, C.POINTER(i64)], i32),
             "hrs_profile_enable": ([vp, i32], i32),
             "hrs_profile_read": ([vp, C.POINTER(dbl), C.POINTER(i64)], i32),

@@ -115,6 +115,7 @@ extern "C" int hrs_ctx_set_peer(hrs_ctx* ctx, hrs_ctx* peer) {
     HRS_REQUIRE(!peer || peer->device == ctx->device, "hrs_ctx_set_peer: contexts on different devices");
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     if (!ctx->scan_done) HRS_CHECK_HIP(hipEventCreateWithFlags(&ctx->scan_done, hipEventDisableTiming));
+    if (!ctx->pre_done) HRS_CHECK_HIP(hipEventCreateWithFlags(&ctx->pre_done, hipEventDisableTiming));
     if (ctx->peer) ctx->peer->waiter = nullptr;
     ctx->peer = peer;
     if (peer) {
@@ -132,6 +133,7 @@ extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->scan_done) (void)hipEventDestroy(ctx->scan_done);
+    if (ctx->pre_done) (void)hipEventDestroy(ctx->pre_done);
     if (ctx->ws_partial.ptr) (void)hipFree(ctx->ws_partial.ptr);
     if (ctx->ws_mfma.ptr) (void)hipFree(ctx->ws_mfma.ptr);
     if (ctx->ws_keys.ptr) (void)hipFree(ctx->ws_keys.ptr);
@@ -211,14 +213,40 @@ extern "C" int hrs_unpack_keys(hrs_ctx* ctx, const uint64_t* keys_dev, int64_t n
     return HRS_OK;
 }
 
+// AUTO: large batches take the matrix cores.  Up to four queries: one pass of the fp64 streaming scan over the
+// fp32 rows -- unless streaming the shadow (a quarter or half of the bytes) plus the fixed cost of the
+// candidate machinery (~0.16 ms) is faster.  Measured cross-overs in elements of the corpus:
+// int8 shadow 3e8 (one or two queries) and 1.5e8 (three or four); bf16 shadow 6e8 and 2e8.
+static bool pick_mfma(const hrs_corpus* c, int B, int k, int mode) {
+    bool use_mfma;
+    if (mode == HRS_MODE_EXACT)
+        use_mfma = false;
+    else if (mode == HRS_MODE_MFMA)
+        use_mfma = true;
+    else {
+        const double elems = (double)c->N * c->D;
+        const bool i8 = c->kind == HRS_SHADOW_I8;
+        const double cross = B <= 2 ? (i8 ? 3e8 : 6e8) : (i8 ? 1.5e8 : 2e8);
+        use_mfma = c->N >= 65536 && (B > 4 || elems >= cross);
+    }
+    if (use_mfma && (c->N < 4096 || c->N < (int64_t)k * 64)) use_mfma = false;
+    return use_mfma;
+}
+
+static int check_topk_args(const char* fn, hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space, int mode) {
+    HRS_REQUIRE(ctx && c, "%s: null handle", fn);
+    HRS_REQUIRE(B >= 0 && (B == 0 || Q_dev), "%s: B=%d with null queries", fn, B);
+    HRS_REQUIRE(k >= 1 && k <= HRS_MAX_K, "%s: k=%d outside [1, %d]", fn, k, HRS_MAX_K);
+    HRS_REQUIRE(space >= 0 && space <= 2, "%s: unknown space %d", fn, space);
+    HRS_REQUIRE(mode >= 0 && mode <= 2, "%s: unknown mode %d", fn, mode);
+    return HRS_OK;
+}
+
 extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
                               const uint8_t* row_mask_dev, int mode, uint64_t* keys_dev, float* dist_dev,
                               int64_t* rows_dev, void* stream) {
-    HRS_REQUIRE(ctx && c, "hrs_score_topk: null handle");
-    HRS_REQUIRE(B >= 0 && (B == 0 || Q_dev), "hrs_score_topk: B=%d with null queries", B);
-    HRS_REQUIRE(k >= 1 && k <= HRS_MAX_K, "hrs_score_topk: k=%d outside [1, %d]", k, HRS_MAX_K);
-    HRS_REQUIRE(space >= 0 && space <= 2, "hrs_score_topk: unknown space %d", space);
-    HRS_REQUIRE(mode >= 0 && mode <= 2, "hrs_score_topk: unknown mode %d", mode);
+    int rc = check_topk_args("hrs_score_topk", ctx, c, Q_dev, B, k, space, mode);
+    if (rc) return rc;
     if (B == 0) return HRS_OK;
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -228,27 +256,53 @@ extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, i
         if (rc0) return rc0;
         keys = (uint64_t*)ctx->ws_keys.ptr;
     }
-    bool use_mfma;
-    if (mode == HRS_MODE_EXACT)
-        use_mfma = false;
-    else if (mode == HRS_MODE_MFMA)
-        use_mfma = true;
-    else {
-        // Large batches: the matrix cores.  Up to four queries: one pass of the fp64 streaming scan over the
-        // fp32 rows -- unless streaming the shadow (a quarter or half of the bytes) plus the fixed cost of the
-        // candidate machinery (~0.16 ms) is faster.  Measured cross-overs in elements of the corpus:
-        // int8 shadow 3e8 (one or two queries) and 1.5e8 (three or four); bf16 shadow 6e8 and 2e8.
-        const double elems = (double)c->N * c->D;
-        const bool i8 = c->kind == HRS_SHADOW_I8;
-        const double cross = B <= 2 ? (i8 ? 3e8 : 6e8) : (i8 ? 1.5e8 : 2e8);
-        use_mfma = c->N >= 65536 && (B > 4 || elems >= cross);
-    }
-    if (use_mfma && (c->N < 4096 || c->N < (int64_t)k * 64)) use_mfma = false;
-
-    int rc = use_mfma ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st)
-                      : hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, st);
+    rc = pick_mfma(c, B, k, mode) ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st)
+                                  : hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, st);
     if (rc == HRS_OK && (dist_dev || rows_dev))
         rc = hrs_unpack_keys(ctx, keys, (int64_t)B * k, dist_dev, rows_dev, stream);
+    return rc;
+}
+
+extern "C" int hrs_score_topk_begin(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
+                                    const uint8_t* row_mask_dev, int mode, void* stream) {
+    int rc = check_topk_args("hrs_score_topk_begin", ctx, c, Q_dev, B, k, space, mode);
+    if (rc) return rc;
+    HRS_REQUIRE(!ctx->pending.active, "hrs_score_topk_begin: the previous call on this context was not finished");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    ctx->pending.c = c;
+    ctx->pending.Q = Q_dev;
+    ctx->pending.mask = row_mask_dev;
+    ctx->pending.B = B;
+    ctx->pending.k = k;
+    ctx->pending.space = space;
+    ctx->pending.mode = mode;
+    // what cannot be split (the exact scan, more than one chunk of queries) runs whole in _finish
+    ctx->pending.split = B > 0 && B <= 1024 && c->shadow && ctx->num_cu == HRS_NUM_CU && pick_mfma(c, B, k, mode);
+    if (ctx->pending.split) {
+        rc = hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, (hipStream_t)stream, HRS_PHASE_SCAN);
+        if (rc) return rc;
+    }
+    ctx->pending.active = true;
+    return HRS_OK;
+}
+
+extern "C" int hrs_score_topk_finish(hrs_ctx* ctx, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev, void* stream) {
+    HRS_REQUIRE(ctx, "hrs_score_topk_finish: null ctx");
+    HRS_REQUIRE(ctx->pending.active, "hrs_score_topk_finish: no call was begun on this context");
+    const auto p = ctx->pending;
+    ctx->pending.active = false;
+    if (!p.split)
+        return hrs_score_topk(ctx, p.c, p.Q, p.B, p.k, p.space, p.mask, p.mode, keys_dev, dist_dev, rows_dev, stream);
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    uint64_t* keys = keys_dev;
+    if (!keys) {
+        int rc0 = hrs_ws_reserve(ctx, &ctx->ws_keys, (size_t)p.B * p.k * sizeof(uint64_t));
+        if (rc0) return rc0;
+        keys = (uint64_t*)ctx->ws_keys.ptr;
+    }
+    int rc = hrs_launch_mfma(ctx, p.c, p.Q, p.B, p.k, p.space, p.mask, keys, (hipStream_t)stream, HRS_PHASE_TAIL);
+    if (rc == HRS_OK && (dist_dev || rows_dev))
+        rc = hrs_unpack_keys(ctx, keys, (int64_t)p.B * p.k, dist_dev, rows_dev, stream);
     return rc;
 }
 

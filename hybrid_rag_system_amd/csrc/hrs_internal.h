@@ -53,6 +53,17 @@ struct hrs_ctx {
     hrs_ctx* waiter = nullptr;  // the context whose `peer` this one is (cleared when either is destroyed)
     hipEvent_t scan_done = nullptr;
     bool scan_recorded = false;
+    // two-phase calls (hrs_score_topk_begin / _finish): the tail of a call waits until the waiter's next
+    // scan has passed its sampled passes, so that it runs under that scan's main pass
+    hipEvent_t pre_done = nullptr;
+    bool pre_recorded = false;
+    struct {
+        bool active = false, split = false;
+        hrs_corpus* c = nullptr;
+        const float* Q = nullptr;
+        const uint8_t* mask = nullptr;
+        int B = 0, k = 0, space = 0, mode = 0;
+    } pending;
     // optional kernel timing (hrs_profile_*): event pairs around the dominant scan kernel
     bool profile = false;
     std::vector<hipEvent_t> ev_start, ev_stop;
@@ -157,7 +168,10 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 // Launchers implemented in the kernel files.
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st);
+// phase: HRS_PHASE_ALL the whole call; HRS_PHASE_SCAN up to and including the main pass (B <= 1024);
+// HRS_PHASE_TAIL the rest of a call whose scan phase ran with the same arguments
+enum { HRS_PHASE_ALL = 0, HRS_PHASE_SCAN = 1, HRS_PHASE_TAIL = 2 };
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                    uint64_t* keys_out, hipStream_t st);
+                    uint64_t* keys_out, hipStream_t st, int phase = HRS_PHASE_ALL);
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st);
 void hrs_free_shadow(hrs_corpus* c);

@@ -51,7 +51,11 @@ template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 #ifndef HRS_SCAN_RING_BYTES
 #define HRS_SCAN_RING_BYTES (128 * 1024)
 #endif
-constexpr int scan_nbuf(int tile_bytes) { return tile_bytes * 5 <= HRS_SCAN_RING_BYTES ? 5 : (tile_bytes * 4 <= HRS_SCAN_RING_BYTES ? 4 : 3); }
+// The kernels with two query tiles per wave serve large batches, which the matrix cores bound: they keep to
+// three tiles (72 KB at depth 384), which leaves LDS for a re-score workgroup of the previous batch on the CU.
+constexpr int scan_nbuf(int tile_bytes, int qt) {
+    return qt == 2 ? 3 : (tile_bytes * 5 <= HRS_SCAN_RING_BYTES ? 5 : (tile_bytes * 4 <= HRS_SCAN_RING_BYTES ? 4 : 3));
+}
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     constexpr int NW = 8;                     // waves per workgroup (256 * QT queries)
     constexpr int RB = KS * 32;               // row bytes
     constexpr int TILE_BYTES = TR * RB;
-    constexpr int NBUF = scan_nbuf(TILE_BYTES);
+    constexpr int NBUF = scan_nbuf(TILE_BYTES, QT);
     constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
     constexpr int NSUB = TR / 32;
     constexpr int PPR = 2 * KS;               // 16-byte pieces per row
@@ -1042,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
 
 template <int KS, int TR, bool I8, int QT>
 static int launch_scan_qt(const MfmaArgs& a, int mode, hipStream_t st) {
-    const size_t lds = (size_t)scan_nbuf(TR * KS * 32) * TR * KS * 32;
+    const size_t lds = (size_t)scan_nbuf(TR * KS * 32, QT) * TR * KS * 32;
     static bool attr_set = false;
     if (!attr_set) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 0, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1099,7 +1103,12 @@ static int scan_mark_done(hrs_ctx* ctx, hipStream_t st) {
 }
 
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                    uint64_t* keys_out, hipStream_t st) {
+                    uint64_t* keys_out, hipStream_t st, int phase) {
+    const bool do_scan = phase != HRS_PHASE_TAIL, do_tail = phase != HRS_PHASE_SCAN;
+    if (phase != HRS_PHASE_ALL && (!c->shadow || ctx->num_cu != HRS_NUM_CU || B > 1024)) {
+        hrs_set_error("hrs_launch_mfma: a two-phase call needs a shadow and at most 1024 queries");
+        return HRS_ERR_ARG;
+    }
     if (!c->shadow || ctx->num_cu != HRS_NUM_CU) {
         // no matrix-core kernel for this shape: the exact scan gives the same answer
         return hrs_launch_exact(ctx, c, Q, B, k, space, mask, nullptr, nullptr, keys_out, st);
@@ -1136,7 +1145,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     int32_t* qlist = (int32_t*)(ws + o_qlist);
 
     const int64_t tiles = (c->N + TR - 1) / TR;
-    if (ctx->peer && ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
+    if (do_scan && ctx->peer && ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
+    // the tail of a two-phase call starts once the scan that waits for this one has set its thresholds: it then
+    // runs under that scan's main pass instead of beside its sampled passes
+    if (phase == HRS_PHASE_TAIL && ctx->waiter && ctx->waiter->pre_recorded)
+        HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->waiter->pre_done, 0));
     for (int qbase = 0; qbase < B; qbase += BC) {
         const int bc = B - qbase < BC ? B - qbase : BC;
         const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
@@ -1153,7 +1166,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         z.n[1] = 64;
         z.p[2] = qbase == 0 ? (int32_t*)ctx->stats_dev : nullptr;
         z.n[2] = 16;
-        if (i8)
+        if (!do_scan) {
+        } else if (i8)
             hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                                bpad, Dpad, (int8_t*)(ws + o_qb), (double*)(ws + o_qn), (float*)(ws + o_qs),
                                (float*)(ws + o_kq), z);
@@ -1203,6 +1217,10 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             if (r) return r;
             hipLaunchKernelGGL(k_raise_tau, dim3((bpad + 255) / 256), dim3(256), 0, st, (float*)(ws + o_tau),
                                (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss2, HRS_CAND_CAP / 2);
+            if (phase == HRS_PHASE_SCAN && ctx->pre_done) {
+                HRS_CHECK_HIP(hipEventRecord(ctx->pre_done, st));
+                ctx->pre_recorded = true;
+            }
             return HRS_OK;
         };
 #define HRS_SCAN(KS_, TR_, I8_)                                                                      \
@@ -1214,7 +1232,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         hrs_prof_end(ctx, st);                                                                       \
         if (rc) return rc;                                                                           \
     } break;
-        if (wide) {
+        if (!do_scan) {
+        } else if (wide) {
             static bool attr_set = false;
             const int lds = 4 * 32 * 1024;
             if (!attr_set) {
@@ -1261,7 +1280,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             }
         }
 #undef HRS_SCAN
-        if (qbase + BC >= B && (rc = scan_mark_done(ctx, st))) return rc;
+        if (do_scan && qbase + BC >= B && (rc = scan_mark_done(ctx, st))) return rc;
+        if (!do_tail) continue;
         SelectArgs s;
         s.C = c->C;
         s.Q = Q;
@@ -1293,6 +1313,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         if (rc) return rc;
         HRS_CHECK_HIP(hipGetLastError());
     }
+    if (!do_tail) return HRS_OK;
     // queries that could not be proven take the exact scan (device-side count; usually zero)
     return hrs_launch_exact(ctx, c, Q, B, k, space, mask, qlist, nflag, keys_out, st);
 }

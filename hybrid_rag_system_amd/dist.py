@@ -76,10 +76,20 @@ class ShardedHybrid:
         self.engine, self.corpus, self.postings, self.group = engine, corpus, postings, group
 
     def step(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
-        e = self.engine
-        c = 2 * n
+        self.begin(queries, q_terms, q_term_offs, n, boost, space, mode)
+        return self.finish()
+
+    def begin(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
+        """The scan of a step (hrs_score_topk_begin); `finish` on the same stream does the rest."""
         # local top-2n of this shard is a superset of the shard's members of the global top-2n
-        _, rows, keys = e.score_topk(self.corpus, queries, c, space=space, mode=mode, want_keys=True)
+        self.engine.score_topk_begin(self.corpus, queries, 2 * n, space=space, mode=mode)
+        self._open = (q_terms, q_term_offs, n, boost)
+
+    def finish(self):
+        e = self.engine
+        q_terms, q_term_offs, n, boost = self._open
+        self._open = None
+        _, rows, keys = e.score_topk_finish(want_keys=True)
         counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
         if self.group is not False and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             gk, gc = allgather_candidates(keys, counts, self.group)
@@ -94,10 +104,13 @@ class HybridPipeline:
 
     A batch is a chain of kernels with very different appetites: the matrix-core scan fills the MFMA
     pipes, the candidate sort / gather / exact re-score that follows is bound by the latency of
-    scattered row reads.  Run back to back on one stream they leave each other's resource idle; on two
-    streams the tail of batch i overlaps the scan of batch i + 1 (both fit a CU's LDS and registers
-    together).  Each batch still runs every kernel of ShardedHybrid.step and results are identical;
-    `submit` returns that step's tensors, valid once `drain()` (or the stream) has been waited for.
+    scattered row reads.  The scans take turns (hrs_ctx_set_peer); `submit` begins batch i + 1 on the
+    next stream and only then enqueues the tail of batch i, which the library holds back until batch
+    i + 1 has its thresholds: the tail then runs under the next main pass (both fit a CU's LDS and
+    registers together) instead of beside the sampled passes that precede it.  Every batch runs every
+    kernel of ShardedHybrid.step and results are identical.  `submit` returns the tensors of the
+    PREVIOUS batch (None for the first); `drain()` finishes the last one, waits for the streams on the
+    caller's stream and returns its tensors.
     """
 
     def __init__(self, engines, corpus, postings, group=None):
@@ -107,15 +120,31 @@ class HybridPipeline:
             if len(engines) > 1:
                 e.set_peer(engines[j - 1])
         self.n = 0
+        self._open = None  # lane with a begun, unfinished batch
+
+    def _finish_open(self):
+        if self._open is None:
+            return None
+        searcher, stream = self._open
+        self._open = None
+        with torch.cuda.stream(stream):
+            return searcher.finish()
 
     def submit(self, queries, q_terms, q_term_offs, n, **kw):
         searcher, stream = self.lanes[self.n % len(self.lanes)]
         self.n += 1
+        if len(self.lanes) == 1:
+            prev = self._finish_open()
         stream.wait_stream(torch.cuda.current_stream())  # the inputs were produced on the caller's stream
         with torch.cuda.stream(stream):
-            out = searcher.step(queries, q_terms, q_term_offs, n, **kw)
-        return out
+            searcher.begin(queries, q_terms, q_term_offs, n, **kw)
+        if len(self.lanes) > 1:
+            prev = self._finish_open()  # after the next scan has been enqueued
+        self._open = (searcher, stream)
+        return prev
 
     def drain(self):
+        last = self._finish_open()
         for _, stream in self.lanes:
             torch.cuda.current_stream().wait_stream(stream)
+        return last

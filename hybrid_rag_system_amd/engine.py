@@ -177,6 +177,31 @@ class Engine:
         )
         return (dist, rows, keys) if want_keys else (dist, rows)
 
+    def score_topk_begin(self, corpus, queries, k, space="l2", mask=None, mode="auto"):
+        """First half of score_topk (the scan); `queries` and `mask` must stay alive until score_topk_finish."""
+        if not (queries.is_cuda and queries.dtype == torch.float32 and queries.dim() == 2 and queries.is_contiguous()):
+            raise ValueError("queries must be a contiguous fp32 [B, D] CUDA tensor")
+        if queries.shape[1] != corpus.dim:
+            raise ValueError(f"query dim {queries.shape[1]} != corpus dim {corpus.dim}")
+        m = {"auto": N.MODE_AUTO, "exact": N.MODE_EXACT, "mfma": N.MODE_MFMA}[mode]
+        N.check(
+            N.lib().hrs_score_topk_begin(self._ctx, corpus._h, _ptr(queries), queries.shape[0], k, N.SPACES[space], _ptr(mask), m, _stream()),
+            "hrs_score_topk_begin",
+        )
+        self._open_call = (queries, mask, queries.shape[0], k)
+
+    def score_topk_finish(self, want_keys=False):
+        """Second half (sort, exact re-score, proof, fallback) on the same stream -> what score_topk returns."""
+        if getattr(self, "_open_call", None) is None:
+            raise ValueError("score_topk_finish without score_topk_begin")
+        _, _, B, k = self._open_call
+        dist = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        rows = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        keys = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        N.check(N.lib().hrs_score_topk_finish(self._ctx, _ptr(keys), _ptr(dist), _ptr(rows), _stream()), "hrs_score_topk_finish")
+        self._open_call = None
+        return (dist, rows, keys) if want_keys else (dist, rows)
+
     def score_stats(self):
         out = (C.c_int64 * 3)()
         N.check(N.lib().hrs_score_stats(self._ctx, _stream(), out), "hrs_score_stats")

@@ -126,6 +126,19 @@ int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, 
                    const uint8_t* row_mask_dev, int mode, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev,
                    void* stream);
 
+/* hrs_score_topk in two halves, for callers that pipeline batches over two contexts joined by
+ * hrs_ctx_set_peer (no counterpart in the reference, which serves one query per process,
+ * scripts/chromadb_helper.py:591-684).  _begin launches the scan (thresholds from sampled passes, then
+ * the main pass); _finish, on the same stream, launches the rest (candidate sort, exact re-score, proof,
+ * fallback) and writes the outputs of hrs_score_topk.  When batch i+1 is begun on the peer context before
+ * batch i is finished, the tail of batch i waits for the thresholds of batch i+1 and then runs under that
+ * scan's main pass, whose matrix-core work it barely disturbs.  One call may be open per context; Q_dev and
+ * the mask must stay valid until _finish; calls that cannot be split (exact mode, more than 1024 queries)
+ * run whole in _finish.  Results are those of hrs_score_topk. */
+int hrs_score_topk_begin(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
+                         const uint8_t* row_mask_dev, int mode, void* stream);
+int hrs_score_topk_finish(hrs_ctx* ctx, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev, void* stream);
+
 /* Counters of the last MFMA-mode call on this ctx, valid after the stream has been waited for:
  * out[0] = queries that took the exact fallback, out[1] = largest candidate count of a query,
  * out[2] = queries whose candidate list overflowed. Waits for `stream`. */

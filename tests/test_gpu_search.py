@@ -339,14 +339,39 @@ def test_two_stream_pipeline_equals_single_stream(eng):
     torch.cuda.synchronize()
     eng2 = Engine(0)
     pipe = HybridPipeline([eng, eng2], corpus, post, group=False)
-    got = [pipe.submit(q, qterms, qoffs, keep, mode="mfma") for q in batches]
-    pipe.drain()
+    got = [r for r in (pipe.submit(q, qterms, qoffs, keep, mode="mfma") for q in batches) if r is not None]  # batch i comes back from submit i + 1
+    got.append(pipe.drain())
+    assert len(got) == len(batches)
     torch.cuda.synchronize()
     for w, g in zip(want, got):
         for key in ("cand_rows", "cand_dist", "cand_counts", "perm", "combined"):
             assert torch.equal(w[key], g[key]), key
     eng.set_peer(None)
     eng2.close()
+    corpus.close()
+
+
+def test_two_phase_call_equals_single_call(eng):
+    """hrs_score_topk_begin + _finish give what hrs_score_topk gives, whether the call can be split (matrix-core
+    path, one chunk) or not (exact path, more than 1024 queries); one call may be open per context."""
+    from hybrid_rag_system_amd._native import HrsError
+
+    rng = np.random.default_rng(77)
+    n, d = 70_000, 384
+    corpus = eng.corpus(torch.from_numpy(_unit(rng, n, d)).cuda())
+    mask = torch.from_numpy((rng.random(n) < 0.5).astype(np.uint8)).cuda()
+    for b, mode, m in ((96, "mfma", None), (300, "auto", None), (3, "auto", None), (64, "mfma", mask), (1100, "mfma", None), (5, "exact", None)):
+        q = torch.from_numpy(_unit(rng, b, d)).cuda()
+        want = eng.score_topk(corpus, q, 10, mode=mode, mask=m, want_keys=True)
+        eng.score_topk_begin(corpus, q, 10, mode=mode, mask=m)
+        with pytest.raises(HrsError, match="not finished"):
+            eng.score_topk_begin(corpus, q, 10, mode=mode, mask=m)
+        got = eng.score_topk_finish(want_keys=True)
+        torch.cuda.synchronize()
+        for w, g in zip(want, got):
+            assert torch.equal(w, g), (b, mode)
+    with pytest.raises(ValueError):
+        eng.score_topk_finish()
     corpus.close()
 
 
