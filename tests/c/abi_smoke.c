@@ -33,7 +33,16 @@ int main(void) {
     CHECK_HRS(hrs_corpus_register(ctx, C, N, D, 0, NULL, &corpus));
     CHECK_HRS(hrs_score_topk(ctx, corpus, Q, B, K, HRS_SPACE_L2, NULL, HRS_MODE_MFMA, k1, dist, rows, NULL));
     CHECK_HRS(hrs_score_topk(ctx, corpus, Q, B, K, HRS_SPACE_L2, NULL, HRS_MODE_EXACT, k2, NULL, NULL, NULL));
+    /* the same call in two halves, as a pipelining caller issues it */
+    uint64_t* k3 = NULL;
+    CHECK_HIP(hipMalloc((void**)&k3, (size_t)B * K * sizeof(uint64_t)));
+    CHECK_HRS(hrs_score_topk_begin(ctx, corpus, Q, B, K, HRS_SPACE_L2, NULL, HRS_MODE_MFMA, NULL));
+    if (hrs_score_topk_begin(ctx, corpus, Q, B, K, HRS_SPACE_L2, NULL, HRS_MODE_MFMA, NULL) != HRS_ERR_ARG) { printf("a second begin was accepted\n"); return 4; }
+    CHECK_HRS(hrs_score_topk_finish(ctx, k3, NULL, NULL, NULL));
     CHECK_HIP(hipDeviceSynchronize());
+    uint64_t h3[16 * 10];
+    CHECK_HIP(hipMemcpy(h3, k3, sizeof h3, hipMemcpyDeviceToHost));
+    hipFree(k3);
     uint64_t h1[16 * 10], h2[16 * 10];
     float hd[16 * 10];
     int64_t hr[16 * 10];
@@ -43,6 +52,7 @@ int main(void) {
     CHECK_HIP(hipMemcpy(hr, rows, sizeof hr, hipMemcpyDeviceToHost));
     int bad = 0;
     if (memcmp(h1, h2, sizeof h1) != 0) { printf("the two scoring paths disagree\n"); bad = 1; }
+    if (memcmp(h1, h3, sizeof h1) != 0) { printf("the two-phase call disagrees\n"); bad = 1; }
     for (int b = 0; b < B; ++b) {
         if (hr[b * K] != 1000 * b + 7 || hd[b * K] != 0.0f) { printf("query %d: first hit row %lld dist %g\n", b, (long long)hr[b * K], hd[b * K]); bad = 1; }
         for (int j = 1; j < K; ++j)
