@@ -88,12 +88,21 @@ def cpu_baseline(corpus_matrix, terms, queries, q_terms, q_offs, n_keep, n_total
     so.fuse_sort(d, cnt, np.diff(qo), n_keep, 0.3)
     dt = time.perf_counter() - t0
     qps_full = bs / dt * (ns / n_total)  # linear in corpus rows
+    # beside it, what a CPU vector store would do at best: one fp32 sgemm (all host threads) + top-k; not
+    # bit-comparable with the oracle (fp32 accumulation), reported for scale only
+    tq, tc = torch.from_numpy(Q), torch.from_numpy(C)
+    (tq @ tc[:1000].T)
+    t0 = time.perf_counter()
+    torch.topk(2.0 - 2.0 * (tq @ tc.T), 2 * n_keep, dim=1, largest=False)
+    dts = time.perf_counter() - t0
     return {
         "value": qps_full,
         "unit": "queries/s",
         "cores": min(threads, bs),
         "kind": "port",
         "sample": f"oracle/search_oracle.c on {bs} queries x {ns} rows x {C.shape[1]} dims in {dt:.2f}s, scaled linearly to {n_total} rows",
+        "sgemm_topk_queries_per_s": bs / dts * (ns / n_total),
+        "sgemm_threads": torch.get_num_threads(),
     }
 
 
