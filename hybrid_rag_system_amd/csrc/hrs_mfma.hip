@@ -51,10 +51,13 @@ template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 #ifndef HRS_SCAN_RING_BYTES
 #define HRS_SCAN_RING_BYTES (128 * 1024)
 #endif
-// The kernels with two query tiles per wave serve large batches, which the matrix cores bound: they keep to
-// three tiles (72 KB at depth 384), which leaves LDS for a re-score workgroup of the previous batch on the CU.
+// The kernels with two query tiles per wave serve large batches, which the matrix cores bound.  There the
+// workgroup barrier at every tile boundary costs a tenth of the time (eight waves wait for the slowest), so
+// these kernels synchronise at every second boundary instead: four buffers, two tiles requested at a time.
+// 96 KB at depth 384, which leaves LDS for a re-score workgroup of the previous batch on the CU.
+constexpr bool scan_pairs(int qt) { return qt == 2; }
 constexpr int scan_nbuf(int tile_bytes, int qt) {
-    return qt == 2 ? 3 : (tile_bytes * 5 <= HRS_SCAN_RING_BYTES ? 5 : (tile_bytes * 4 <= HRS_SCAN_RING_BYTES ? 4 : 3));
+    return scan_pairs(qt) ? 4 : (tile_bytes * 5 <= HRS_SCAN_RING_BYTES ? 5 : (tile_bytes * 4 <= HRS_SCAN_RING_BYTES ? 4 : 3));
 }
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
@@ -77,7 +80,7 @@ struct MfmaArgs {
     float* maxima;         // [Bpad][HRS_MAX_STREAMS]
     const float* tau;      // [Bpad]
     int* cnt;              // [Bpad]
-    uint64_t* cand;        // [Bpad][HRS_CAND_CAP]
+    uint64_t* cand;        // [Bpad][HRS_CAND_CAP_BIG]
 };
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     constexpr int RB = KS * 32;               // row bytes
     constexpr int TILE_BYTES = TR * RB;
     constexpr int NBUF = scan_nbuf(TILE_BYTES, QT);
+    constexpr bool PAIR = scan_pairs(QT);     // barrier at every second tile boundary
     constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
     constexpr int NSUB = TR / 32;
     constexpr int PPR = 2 * KS;               // 16-byte pieces per row
@@ -205,16 +209,24 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         if (I8) scale_load(tile_at(0));
 #pragma unroll
         for (int g = 0; g < NBUF; ++g) issue(g, g);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPW) : "memory");
+        // the first tile (PAIR: the first two) has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PAIR ? NBUF - 2 : NBUF - 1) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
         int buf = 0;
         if (q0 >= a.nq) {
             // padding queries only (a small batch): this wave keeps its share of the LDS-DMA ring going and
             // meets the same barriers, and leaves the matrix cores to the waves that hold queries
             for (int64_t n = 0; n + 1 < count; ++n) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
-                __builtin_amdgcn_s_barrier();
-                issue(n + NBUF, buf);
+                if (!PAIR) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue(n + NBUF, buf);
+                } else if (n & 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue(n + 3, (buf + 3) & 3);
+                    issue(n + 4, buf);
+                }
                 buf = buf + 1 == NBUF ? 0 : buf + 1;
             }
         } else {
@@ -268,10 +280,20 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
 #pragma unroll
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
                 } else if (n + 1 < count) {
-                    // tile boundary: tile n+1 has landed once at most one younger tile is outstanding
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                    issue(n + NBUF, buf);  // tile n's buffer is free: every wave has consumed its fragments
+                    if (!PAIR) {
+                        // tile boundary: tile n+1 has landed once the younger tiles alone are outstanding
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        issue(n + NBUF, buf);  // tile n's buffer is free: every wave has consumed its fragments
+                    } else if (n & 1) {
+                        // end of a pair: tiles n+1 and n+2, requested two tiles ago, have landed; behind the barrier
+                        // the buffers of tiles n-1 and n are free for tiles n+3 and n+4.  Between the tiles of a
+                        // pair nothing is awaited: both were complete at the last barrier.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        issue(n + 3, (buf + 3) & 3);
+                        issue(n + 4, buf);
+                    }
                     buf = buf + 1 == NBUF ? 0 : buf + 1;
 #pragma unroll
                     for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
@@ -846,8 +868,8 @@ struct SelectArgs {
     int qbase;           // first query of this chunk
 };
 
-// Two sizes of the same kernel.  The small one (lists up to HRS_CAND_CAP, re-scored prefix up to 1024
-// rows, three workgroups per CU) serves every query first; a query whose list is longer or whose
+// Two sizes of the same kernel.  The small one (lists up to HRS_CAND_CAP, re-scored prefix up to HRS_RESCORE_MAX
+// rows, 60 KB of LDS: one workgroup fits beside a scan workgroup on a CU) serves every query first; a query whose list is longer or whose
 // prefix would have to grow further -- runs of near-duplicate rows around the top -- is deferred to the
 // large one (lists up to HRS_CAND_CAP_BIG, prefix up to 4096, one workgroup per CU), and only what that
 // cannot prove goes to the exact scan.
@@ -860,7 +882,7 @@ struct SelectArgs {
 template <int SPACE, bool BIG>
 __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     constexpr int SCAP = BIG ? HRS_CAND_CAP_BIG : HRS_CAND_CAP;  // candidates sorted in LDS
-    constexpr int RMAX = BIG ? 4096 : 1024;                      // largest re-scored prefix
+    constexpr int RMAX = BIG ? 4096 : HRS_RESCORE_MAX;           // largest re-scored prefix
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
     uint64_t* s = (uint64_t*)sel_smem;                       // [SCAP]
     uint64_t* ek = s + SCAP;                                 // [RMAX]
@@ -1078,7 +1100,7 @@ static int launch_scan(MfmaArgs a, int mode, int qt, const hrs_corpus* c, hipStr
 
 template <int SPACE>
 static int launch_select(const SelectArgs& s, int bc, hipStream_t st) {
-    const int lds_small = (HRS_CAND_CAP + 1024) * 8 + 1024 * 4 + 4 * 64 * 144;
+    const int lds_small = (HRS_CAND_CAP + HRS_RESCORE_MAX) * 8 + 1024 * 4 + 4 * 64 * 144;
     const int lds_big = (HRS_CAND_CAP_BIG + 4096) * 8 + 1024 * 4 + 4 * 64 * 144;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1197,8 +1219,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.lad_inv = (const float*)(ws + o_lad);
         a.hist = (int*)(ws + o_hist);
         const int M = nslices * 2 * (TR / 32);
-        // aim at ~max(384, 6k) rows above tau; expected count ~ ss * M * -ln(1 - j/M)
-        int target = 6 * k > 384 ? 6 * k : 384;
+        // aim at ~max(384, 6k) rows above tau; expected count ~ ss * M * -ln(1 - j/M).  The int8 shadow ranks by
+        // an upper bound that sits ~0.5 sigma above the score: of the rows recorded only about one in fourteen
+        // scores above tau itself, and k of those are needed for the proof -- hence 18k.
+        const int per_k = i8 ? 18 : 6;
+        int target = per_k * k > 384 ? per_k * k : 384;
         int j = (target + ss - 1) / ss;
         if (j < HRS_J_MIN) j = HRS_J_MIN;
         if (j > M / 2) j = M / 2;
@@ -1216,7 +1241,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             a.ss = ss;
             if (r) return r;
             hipLaunchKernelGGL(k_raise_tau, dim3((bpad + 255) / 256), dim3(256), 0, st, (float*)(ws + o_tau),
-                               (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss2, HRS_CAND_CAP / 2);
+                               (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss2, HRS_CAND_CAP_BIG / 4);
             if (phase == HRS_PHASE_SCAN && ctx->pre_done) {
                 HRS_CHECK_HIP(hipEventRecord(ctx->pre_done, st));
                 ctx->pre_recorded = true;

@@ -61,3 +61,18 @@ def test_full_size_sharded_merge_equals_unsharded(world):
     assert torch.equal(merged, want)
     for cp in keep:
         cp.close()
+
+
+@pytest.mark.parametrize("k,b", [(100, 1024), (128, 200), (50, 600)])
+def test_full_size_large_k_stays_on_the_matrix_cores(world, k, b):
+    """Large k over the int8 shadow: the candidate target grows with k, so the proof succeeds without the exact
+    fallback (which would take hundreds of milliseconds for a batch), and a sample equals the exact scan's keys."""
+    eng, m, corpus, q, planted = world
+    qs = q[:b].contiguous()
+    _, _, k1 = eng.score_topk(corpus, qs, k, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    assert st["overflow_queries"] == 0 and st["fallback_queries"] <= b // 100, st
+    sel = torch.tensor([0, 1, 63, 64, 65, b - 1], device="cuda")
+    _, _, k2 = eng.score_topk(corpus, qs[sel].contiguous(), k, mode="exact", want_keys=True)
+    assert torch.equal(k1[sel], k2)
