@@ -455,15 +455,27 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
         typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
         const int rowoff = (int)lds0 + i * ROWB;
         const int vx = h ^ (i & 15);
+        // Large batches are bound by the matrix cores and every barrier is a bubble in all four pipes: the waves
+        // then meet once per tile (two stages), where both stages of the tile have landed and the two buffers of
+        // the previous tile are requested anew.  Small batches are bound by the bytes in flight and keep the
+        // per-stage barrier with three stages outstanding.
+        const bool pairs = a.nq >= 512;
         issue(0);
         issue(1);
-        issue(2);
+        if (!pairs) issue(2);
         f32x16 acc;
         for (int64_t g = 0; g < stages; ++g) {
             const int kc = (int)(g % SPT);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(g + 3);
+            if (!pairs) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(g + 3);
+            } else if (kc == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(g + 2);
+                issue(g + 3);
+            }
             lds_cptr tb[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(rowoff + (int)(g % NBUF) * STAGE + (((2 * c) ^ vx) << 4));
