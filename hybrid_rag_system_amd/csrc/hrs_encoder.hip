@@ -268,18 +268,53 @@ struct GemmWsArgs {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Workgroup -> (token slice, feature group).  The ngroups workgroups that cover the feature groups of one
+// token slice read the same activation tiles at the same pace; consecutive workgroup ids go to the eight
+// XCDs in turn, each with an L2 of its own, so the groups of a slice are given ids that are congruent
+// modulo 8: the slice then comes from HBM once instead of ngroups times.  Workgroups beyond the largest
+// multiple of 8 * ngroups (255 = 240 + 15 for three groups) keep the plain order.
+__device__ __forceinline__ void slice_of_block(int b, int grid, int ngroups, int& fg, int& slice, int& nslices) {
+    const int per_xcd = (grid >> 3) / ngroups;  // whole slices per XCD
+    const int main_blocks = per_xcd * ngroups * 8;
+    nslices = per_xcd * 8 + (grid - main_blocks) / ngroups;
+    if (b < main_blocks) {
+        const int j = b >> 3;
+        fg = j % ngroups;
+        slice = (j / ngroups) * 8 + (b & 7);
+    } else {
+        const int r = b - main_blocks;
+        fg = r % ngroups;
+        slice = per_xcd * 8 + r / ngroups;
+    }
+}
+
+// The 32x32 accumulator leaves a lane (token i, half h) with features 8g + 4h .. 8g + 4h + 3 of every
+// 8-feature piece g: 8 bytes of bf16 per piece.  One v_permlane32_swap per dword between the lanes i and
+// i + 32 gives the lower lane the whole of piece ga and the upper lane the whole of piece gb, so a lane
+// stores 16 bytes and the two lanes of a token 32 contiguous bytes (half as many store instructions).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 piece_exchange(bf16x4 pa, bf16x4 pb) {
+    const u32x2 a = (const u32x2&)pa, b = (const u32x2&)pb;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    u32x4 o;
+    o.x = r0[0];
+    o.y = r1[0];
+    o.z = r0[1];
+    o.w = r1[1];
+    return o;
+}
+
 template <int EPI, bool VW>
 __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
-    constexpr int KS = 24, TR = 64, RB = 768, TILE_BYTES = TR * RB, IPW = 4, PPR = 48, NST = 8;
+    constexpr int KS = 24, TR = 64, RB = 768, TILE_BYTES = TR * RB, IPW = 4, PPR = 48, NST = 4;  // NST: stores per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, i = lane & 31;
     const int ngroups = a.N / 384;
-    const int nslices = (int)gridDim.x / ngroups;
-    const int fg = (int)blockIdx.x % ngroups;
-    const int slice = (int)blockIdx.x / ngroups;
-    if (slice >= nslices) return;
+    int fg, slice, nslices;
+    slice_of_block((int)blockIdx.x, (int)gridDim.x, ngroups, fg, slice, nslices);
     const int wfeat = fg * 384 + wv * 32;  // this wave's 32 output features
     constexpr bool vwave = VW;
 
@@ -323,6 +358,66 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     typedef const __attribute__((address_space(3))) char* lds_cptr;
     const int rowoff = (int)lds0 + i * RB;
     const int vx = h ^ (i & 15);
+
+    // epilogue of one 32-token subtile for the outputs without LayerNorm: 4 stores per lane
+    auto epilogue = [&](const f32x16& acc, const int tok0) __attribute__((always_inline)) {
+        if (vwave) {
+            // lane <-> feature d = i (+ head), registers <-> tokens tok0 + (r&3) + 8(r>>2) + 4h
+            const int head = (wfeat - 768) >> 5;
+            const int b = tok0 / a.S, sp0 = tok0 % a.S;  // 32-token tiles never straddle sequences (S % 32 == 0)
+            const int kt = sp0 >> 5;
+            __bf16* vb = a.vf + (((size_t)b * ENC_HEADS + head) * (a.S >> 5) + kt) * 1024 + (h * 32 + i) * 8;
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)(acc[8 * g2 + e] + bias_lds[wv * 32 + i]);
+                *(bf16x8*)(vb + g2 * 512) = o;
+            }
+        } else {
+            const int token = tok0 + i;
+            bf16x4 o[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
+                float v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
+                float v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
+                if (EPI == EPI_GELU) {
+                    f32x2 g01, g23;
+                    g01.x = v0;
+                    g01.y = v1;
+                    g23.x = v2;
+                    g23.y = v3;
+                    g01 = gelu_erf2(g01);
+                    g23 = gelu_erf2(g23);
+                    v0 = g01.x;
+                    v1 = g01.y;
+                    v2 = g23.x;
+                    v3 = g23.y;
+                } else if (EPI == EPI_QKV) {
+                    const float sc = fg == 0 ? a.qscale : 1.0f;
+                    v0 *= sc;
+                    v1 *= sc;
+                    v2 *= sc;
+                    v3 *= sc;
+                }
+                o[g][0] = (__bf16)v0;
+                o[g][1] = (__bf16)v1;
+                o[g][2] = (__bf16)v2;
+                o[g][3] = (__bf16)v3;
+            }
+            // lower lane: pieces 0 and 2, upper lane: pieces 1 and 3 (features 8 * piece .. + 7 of this wave's 32)
+            __bf16* dst;
+            if (EPI == EPI_QKV) {
+                const int b = token / a.S, sp = token % a.S;
+                dst = (fg == 0 ? a.q : a.k) + (((size_t)b * ENC_HEADS + wv) * a.S + sp) * ENC_DH;  // this wave's 32 features are head wv
+            } else {
+                dst = a.C + (size_t)token * a.N + wfeat;
+            }
+            *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
+            *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
+        }
+    };
 
     issue(0, 0);
     issue(1, 1);
@@ -388,20 +483,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
 
             const int tok0 = (t_begin + n) * TR + sb * 32;
-            if (vwave) {
-                // lane <-> feature d = i (+ head), registers <-> tokens tok0 + (r&3) + 8(r>>2) + 4h
-                const int head = (wfeat - 768) >> 5;
-                const int b = tok0 / a.S, sp0 = tok0 % a.S;  // 32-token tiles never straddle sequences (S % 32 == 0)
-                const int kt = sp0 >> 5;
-                __bf16* vb = a.vf + (((size_t)b * ENC_HEADS + head) * (a.S >> 5) + kt) * 1024 + (h * 32 + i) * 8;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[4 * g + e] + bias_lds[wv * 32 + i]);
-                    *(bf16x4*)(vb + (g >> 1) * 512 + (g & 1) * 4) = o;
-                }
-            } else if (EPI == EPI_LN) {
+            if (EPI == EPI_LN) {
                 const int token = tok0 + i;
                 float v[16];
                 // residual of this subtile has landed; younger: nothing (subtile 0) or the DMA issued below (subtile 1)
@@ -438,18 +520,20 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 pb ^= 1;
                 const float mean = t1 * (1.0f / 384.0f);
                 const float rstd = rsqrtf(fmaxf(t2 * (1.0f / 384.0f) - mean * mean, 0.f) + a.eps);
+                bf16x4 o[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f = wv * 32 + 8 * g + 4 * h;
                     const float4 gv = *(const float4*)(bias_lds + 384 + f);
                     const float4 be = *(const float4*)(bias_lds + 768 + f);
-                    bf16x4 o;
-                    o[0] = (__bf16)((v[4 * g + 0] - mean) * rstd * gv.x + be.x);
-                    o[1] = (__bf16)((v[4 * g + 1] - mean) * rstd * gv.y + be.y);
-                    o[2] = (__bf16)((v[4 * g + 2] - mean) * rstd * gv.z + be.z);
-                    o[3] = (__bf16)((v[4 * g + 3] - mean) * rstd * gv.w + be.w);
-                    *(bf16x4*)(a.C + (size_t)token * 384 + f) = o;
+                    o[g][0] = (__bf16)((v[4 * g + 0] - mean) * rstd * gv.x + be.x);
+                    o[g][1] = (__bf16)((v[4 * g + 1] - mean) * rstd * gv.y + be.y);
+                    o[g][2] = (__bf16)((v[4 * g + 2] - mean) * rstd * gv.z + be.z);
+                    o[g][3] = (__bf16)((v[4 * g + 3] - mean) * rstd * gv.w + be.w);
                 }
+                __bf16* dst = a.C + (size_t)token * 384 + wv * 32;
+                *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
+                *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
                 if (sb == 0) {
                     // residual of the second subtile, then the tile two ahead (its buffer was freed by the barrier at the top)
 #pragma unroll
@@ -458,45 +542,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                     issue(n + 2, nb);
                 }
             } else {
-                const int token = tok0 + i;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = wfeat + 8 * g + 4 * h;
-                    const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
-                    float v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
-                    float v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
-                    bf16x4 o;
-                    if (EPI == EPI_GELU) {
-                        f32x2 g01, g23;
-                        g01.x = v0;
-                        g01.y = v1;
-                        g23.x = v2;
-                        g23.y = v3;
-                        g01 = gelu_erf2(g01);
-                        g23 = gelu_erf2(g23);
-                        o[0] = (__bf16)g01.x;
-                        o[1] = (__bf16)g01.y;
-                        o[2] = (__bf16)g23.x;
-                        o[3] = (__bf16)g23.y;
-                        *(bf16x4*)(a.C + (size_t)token * a.N + f) = o;
-                    } else if (EPI == EPI_PLAIN) {
-                        o[0] = (__bf16)v0;
-                        o[1] = (__bf16)v1;
-                        o[2] = (__bf16)v2;
-                        o[3] = (__bf16)v3;
-                        *(bf16x4*)(a.C + (size_t)token * a.N + f) = o;
-                    } else {
-                        const float sc = fg == 0 ? a.qscale : 1.0f;
-                        o[0] = (__bf16)(v0 * sc);
-                        o[1] = (__bf16)(v1 * sc);
-                        o[2] = (__bf16)(v2 * sc);
-                        o[3] = (__bf16)(v3 * sc);
-                        const int hf = f - fg * 384;
-                        const int b = token / a.S, sp = token % a.S;
-                        __bf16* dst = (fg == 0 ? a.q : a.k) + (((size_t)b * ENC_HEADS + (hf >> 5)) * a.S + sp) * ENC_DH + (hf & 31);
-                        *(bf16x4*)dst = o;
-                    }
-                }
+                epilogue(acc, tok0);
             }
         }
         buf = buf + 1 == 3 ? 0 : buf + 1;
@@ -507,7 +553,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
 template <int EPI>
 __global__ __launch_bounds__(768) void k_gemm_ws(GemmWsArgs a) {
     // the V third of the QKV projection is produced with the operands swapped (feature on the lane)
-    if (EPI == EPI_QKV && (int)blockIdx.x % (a.N / 384) == 2)
+    int fg, slice, nslices;
+    slice_of_block((int)blockIdx.x, (int)gridDim.x, a.N / 384, fg, slice, nslices);
+    if (EPI == EPI_QKV && fg == 2)
         gemm_ws_body<EPI, true>(a);
     else
         gemm_ws_body<EPI, false>(a);
@@ -548,8 +596,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, i = lane & 31;
-    const int fg = (int)blockIdx.x % 3;
-    const int slice = (int)blockIdx.x / 3, nslices = (int)gridDim.x / 3;
+    int fg, slice, nslices;
+    slice_of_block((int)blockIdx.x, (int)gridDim.x, 3, fg, slice, nslices);
     const int wfeat = fg * 128 + wv * 32;
 
     bf16x8 wf[SPT * KSS];
@@ -599,9 +647,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
         bool stored = false;
         for (int g = 0; g < stages; ++g) {
             const int kc = g % SPT;
-            // oldest first: DMA(g), DMA(g+1), DMA(g+2), then the 4 stores of a tile finished in stage g-1
+            // oldest first: DMA(g), DMA(g+1), DMA(g+2), then the 2 stores of a tile finished in stage g-1
             if (stored)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW + 4) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW + 2) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
             __builtin_amdgcn_s_barrier();
@@ -637,13 +685,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
                 run(std::integral_constant<int, 2>{});
                 mfma_fence(acc);
                 const int token = (t_begin + g / SPT) * 32 + i;
+                bf16x4 o[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[4 * gq + e] + bz[4 * gq + e]);
-                    *(bf16x4*)(a.C + (size_t)token * ENC_H + wfeat + 8 * gq + 4 * h) = o;
+                    for (int e = 0; e < 4; ++e) o[gq][e] = (__bf16)(acc[4 * gq + e] + bz[4 * gq + e]);
                 }
+                __bf16* dst = a.C + (size_t)token * ENC_H + wfeat;
+                *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
+                *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
                 stored = true;
             }
         }
@@ -654,9 +704,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
 // ---- attention -----------------------------------------------------------------------------------
 // One workgroup (4 waves) per (sequence, head); a wave owns 32-query tiles. With S <= 256 the whole
 // score row lives in registers: S^T = K Q^T puts the query on the lane, so the row maximum and sum
-// are in-lane reductions plus one exchange between lane halves; P (bf16) then feeds O = P V as the
-// first MFMA operand with no lane movement (the k order of that product is the accumulator's
-// register order, which is the order V was stored in by the QKV epilogue).
+// are in-lane reductions plus one exchange between lane halves; P (bf16) then feeds O^T = V^T P^T as the
+// second MFMA operand with no lane movement (the k order of that product is the accumulator's
+// register order, which is the order V was stored in by the QKV epilogue), so the query is still on the
+// lane in the output, 1/l needs no shuffle and a context row leaves as two 16-byte stores per lane.
 struct AttnArgs {
     const __bf16* q;   // [B][heads][S][32], scaled by log2(e)/sqrt(32)
     const __bf16* k;   // [B][heads][S][32]
@@ -666,8 +717,11 @@ struct AttnArgs {
     int S;
 };
 
+// Two waves per SIMD are asked for so that the register budget is 256: the compiler then keeps the MFMA
+// results in ordinary registers (with a 512-register budget it puts them in the accumulator half and
+// copies every score tile out and every initial value in, 26 register moves per MFMA here).
 template <int NKT>
-__global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
     // K (swizzled: 16-byte piece p of key row r at p ^ ((r >> 2) & 3), so that the 16 rows a
     // ds_read_b128 lane group touches fall on 16 different bank groups) and V (already in fragment
     // order) of this (sequence, head), shared by the four waves and by both passes
@@ -696,6 +750,9 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     const int koff1 = i * 64 + (((2 + h) ^ ((i >> 2) & 3)) << 4);
 
     for (int qt = wv; qt < NKT; qt += 4) {
+        // the key masks of a partial tile are recomputed where they are used: hoisted out of this loop they
+        // are 128 lane masks that no longer fit the scalar registers
+        asm volatile("" : "+s"(len));
         bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + ((qt * 32 + i) * ENC_DH + ks * 16 + h * 8) * 2);
@@ -714,27 +771,25 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[r]);
                 } else {
+                    const int lim = len - kt * 32 - 4 * h;  // register r holds key kt*32 + (r&3) + 8(r>>2) + 4h
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        m = fmaxf(m, key < len ? sc[r] : -1e30f);
-                    }
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, (r & 3) + 8 * (r >> 2) < lim ? sc[r] : -1e30f);
                 }
             }
         }
         m = fmaxf(m, __shfl_xor(m, 32));
         // pass 2: the accumulator starts at -m, so the MFMA result is already s - m
         float l = 0.f;
-        f32x16 o;
+        f32x16 o, negm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             if (kt < nkt) {
                 f32x16 sc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[r] = -m;
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff0), qf[0], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff0), qf[0], negm, 0, 0, 0);
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(klds + kt * 2048 + koff1), qf[1], sc, 0, 0, 0);
                 if (kt * 32 + 32 <= len) {
 #pragma unroll
@@ -743,10 +798,10 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
                         l += sc[r];
                     }
                 } else {
+                    const int lim = len - kt * 32 - 4 * h;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        sc[r] = key < len ? __builtin_amdgcn_exp2f(sc[r]) : 0.f;
+                        sc[r] = (r & 3) + 8 * (r >> 2) < lim ? __builtin_amdgcn_exp2f(sc[r]) : 0.f;
                         l += sc[r];
                     }
                 }
@@ -755,19 +810,24 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
                     bf16x8 pf;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[8 * s2 + e];
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, *(const bf16x8*)(vlds + ((kt * 2 + s2) * 64 + lane) * 16), o, 0, 0, 0);
+                    // O^T = V^T P^T: the query stays on the lane, the registers run over the head's 32 columns
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vlds + ((kt * 2 + s2) * 64 + lane) * 16), pf, o, 0, 0, 0);
                 }
             }
         }
         l += __shfl_xor(l, 32);
-        const float inv = l > 0.f ? 1.0f / l : 0.f;  // per query, held by the lanes whose i is that query
-        // o[r] = O[query qt*32 + (r&3) + 8(r>>2) + 4h][column i]: fetch each row's 1/l from its lane
+        const float inv = l > 0.f ? 1.0f / l : 0.f;  // per query = per lane pair (i, i + 32)
+        // o[r] = O[query qt*32 + i][column (r&3) + 8(r>>2) + 4h]: a lane pair holds the 64 bytes of its query's
+        // context row for this head; two 16-byte stores per lane after the exchange between the halves
+        bf16x4 ob[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float w = __shfl(inv, qi);
-            a.ctx[((size_t)b * S + qt * 32 + qi) * ENC_H + head * ENC_DH + i] = (__bf16)(o[r] * w);
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[g][e] = (__bf16)(o[4 * g + e] * inv);
         }
+        __bf16* dst = a.ctx + ((size_t)b * S + qt * 32 + i) * ENC_H + head * ENC_DH;
+        *(u32x4*)(dst + 8 * h) = piece_exchange(ob[0], ob[1]);
+        *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(ob[2], ob[3]);
     }
 }
 

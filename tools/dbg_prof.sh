@@ -10,6 +10,7 @@ for d in "$@"; do
   echo "== $d"
   rm -rf gpurun_out/prof_dbg
   timeout -k 10 200 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_dbg --output-format csv -- python3 $cmd > gpurun_out/dbg.log 2>&1 || true
-  python3 tools/kstats.py gpurun_out/prof_dbg "$filt"
+  tail -1 gpurun_out/dbg.log
+  python3 tools/kstats.py gpurun_out/prof_dbg $filt
 done
 cp /tmp/libhrs.keep hybrid_rag_system_amd/libhrs.so
