@@ -4,7 +4,7 @@ import numpy as np, torch
 from hybrid_rag_system_amd import weights as W
 from hybrid_rag_system_amd.engine import Engine
 eng = Engine(0); cfg = W.EncoderConfig(); enc = eng.encoder(W.generate(cfg), cfg)
-B, S = 1024, 256
+B, S = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), (int(sys.argv[2]) if len(sys.argv) > 2 else 256)
 rng = np.random.default_rng(0)
 ids = torch.from_numpy(rng.integers(1000, 30000, (B, S)).astype(np.int32)).cuda()
 lens = torch.full((B,), S, dtype=torch.int32, device='cuda')
