@@ -837,7 +837,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per token: lanes 0..47 hold 8 features each (32-byte table reads, one 16-byte store).
+// One wave per token: 384 features = 6 per lane.
 __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, const float* __restrict__ word,
                                                   const float* __restrict__ pos, const float* __restrict__ type0,
                                                   const float* __restrict__ g, const float* __restrict__ bta, int M,
@@ -848,43 +848,26 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, c
     int id = t < Mreal ? ids[t] : 0;
     if (id < 0 || id >= vocab) id = 0;
     const int sp = t % S;
-    const bool on = lane < 48;
-    const int c0 = on ? lane * 8 : 0;
-    float v[8];
+    float v[6];
     float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const float4 w4 = *(const float4*)(word + (size_t)id * ENC_H + c0 + 4 * q);
-        const float4 p4 = *(const float4*)(pos + (size_t)sp * ENC_H + c0 + 4 * q);
-        const float4 t4 = *(const float4*)(type0 + c0 + 4 * q);
-        v[4 * q + 0] = w4.x + p4.x + t4.x;
-        v[4 * q + 1] = w4.y + p4.y + t4.y;
-        v[4 * q + 2] = w4.z + p4.z + t4.z;
-        v[4 * q + 3] = w4.w + p4.w + t4.w;
-    }
-    if (on) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += v[j];
+    for (int j = 0; j < 6; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = word[(size_t)id * ENC_H + c] + pos[(size_t)sp * ENC_H + c] + type0[c];
+        sum += v[j];
     }
     const float mean = wave_sum(sum) * (1.0f / ENC_H);
     float var = 0.f;
-    if (on) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = v[j] - mean;
-            var += d * d;
-        }
+    for (int j = 0; j < 6; ++j) {
+        const float d = v[j] - mean;
+        var += d * d;
     }
     const float rstd = rsqrtf(wave_sum(var) * (1.0f / ENC_H) + eps);
-    if (on) {
-        const float4 g0 = *(const float4*)(g + c0), g1 = *(const float4*)(g + c0 + 4);
-        const float4 b0 = *(const float4*)(bta + c0), b1 = *(const float4*)(bta + c0 + 4);
-        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)((v[j] - mean) * rstd * gg[j] + bb[j]);
-        *(bf16x8*)(x + (size_t)t * ENC_H + c0) = o;
+    for (int j = 0; j < 6; ++j) {
+        const int c = lane + 64 * j;
+        x[(size_t)t * ENC_H + c] = (__bf16)((v[j] - mean) * rstd * g[c] + bta[c]);
     }
 }
 
