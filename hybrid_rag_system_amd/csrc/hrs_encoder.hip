@@ -70,6 +70,32 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 hh = __builtin_elementwise_fma(xc * q, (f32x2)(0.5f), (f32x2)(0.5f));
     return x * hh;
 }
+// Two independent pairs, step by step side by side: a packed fp32 instruction that reads the result of the one
+// before it costs a wait state (the compiler fills it with s_nop), two interleaved chains leave none.
+__device__ __forceinline__ void gelu_erf2x2(f32x2& a, f32x2& b) {
+    f32x2 ac, bc;
+    ac.x = __builtin_amdgcn_fmed3f(a.x, -3.67695526f, 3.67695526f);
+    ac.y = __builtin_amdgcn_fmed3f(a.y, -3.67695526f, 3.67695526f);
+    bc.x = __builtin_amdgcn_fmed3f(b.x, -3.67695526f, 3.67695526f);
+    bc.y = __builtin_amdgcn_fmed3f(b.y, -3.67695526f, 3.67695526f);
+    const f32x2 a2 = ac * ac, b2 = bc * bc;
+    f32x2 qa = __builtin_elementwise_fma(a2, (f32x2)(8.601600188e-08f), (f32x2)(-5.069113089e-06f));
+    f32x2 qb = __builtin_elementwise_fma(b2, (f32x2)(8.601600188e-08f), (f32x2)(-5.069113089e-06f));
+    qa = __builtin_elementwise_fma(qa, a2, (f32x2)(1.296143067e-04f));
+    qb = __builtin_elementwise_fma(qb, b2, (f32x2)(1.296143067e-04f));
+    qa = __builtin_elementwise_fma(qa, a2, (f32x2)(-1.924680215e-03f));
+    qb = __builtin_elementwise_fma(qb, b2, (f32x2)(-1.924680215e-03f));
+    qa = __builtin_elementwise_fma(qa, a2, (f32x2)(1.885473079e-02f));
+    qb = __builtin_elementwise_fma(qb, b2, (f32x2)(1.885473079e-02f));
+    qa = __builtin_elementwise_fma(qa, a2, (f32x2)(-1.317864380e-01f));
+    qb = __builtin_elementwise_fma(qb, b2, (f32x2)(-1.317864380e-01f));
+    qa = __builtin_elementwise_fma(qa, a2, (f32x2)(7.976052351e-01f));
+    qb = __builtin_elementwise_fma(qb, b2, (f32x2)(7.976052351e-01f));
+    const f32x2 ha = __builtin_elementwise_fma(ac * qa, (f32x2)(0.5f), (f32x2)(0.5f));
+    const f32x2 hb = __builtin_elementwise_fma(bc * qb, (f32x2)(0.5f), (f32x2)(0.5f));
+    a = a * ha;
+    b = b * hb;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
     f32x2 v;
     v.x = x;
@@ -388,8 +414,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                     g01.y = v1;
                     g23.x = v2;
                     g23.y = v3;
-                    g01 = gelu_erf2(g01);
-                    g23 = gelu_erf2(g23);
+                    gelu_erf2x2(g01, g23);
                     v0 = g01.x;
                     v1 = g01.y;
                     v2 = g23.x;
