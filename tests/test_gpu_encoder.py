@@ -38,7 +38,7 @@ def _inputs(B, S, seed, full=False):
     return ids, lens
 
 
-@pytest.mark.parametrize("B,S", [(16, 256), (5, 64), (8, 32), (3, 160), (40, 128)])
+@pytest.mark.parametrize("B,S", [(16, 256), (5, 64), (8, 32), (3, 160), (40, 128), (7, 96), (9, 192), (4, 224)])  # every sequence length the attention kernel is instantiated for
 def test_encoder_matches_oracle(setup, B, S):
     eng, enc, w, cfg = setup
     ids, lens = _inputs(B, S, seed=B * 1000 + S)
