@@ -102,6 +102,92 @@ void hrs_oracle_topk(const float* Q, const float* C, int64_t N, int D, int B, in
     }
 }
 
+/*
+ * Same result as hrs_oracle_topk, OQB queries per pass over the rows: every (query, row) chain is
+ * the same sequence of fp64 operations as in hrs_oracle_dist64 (so the keys are bit-identical), but
+ * OQB independent chains keep the FMA pipes busy and a row is read once for OQB queries.
+ * tests/test_search_oracle.py holds it to hrs_oracle_topk.
+ */
+#define OQB 32
+void hrs_oracle_topk_blocked(const float* Q, const float* C, int64_t N, int D, int B, int k, int space,
+                             int64_t row_offset, const uint8_t* mask, uint64_t* out_keys) {
+    const int nblk = (B + OQB - 1) / OQB;
+    /* cosine: the rows' squared norms (one sequential chain per row, as in hrs_oracle_dist64) once per call */
+    double* ncs = NULL;
+    if (space == SPACE_COSINE) {
+        ncs = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+#pragma omp parallel for schedule(static)
+        for (int64_t r4 = 0; r4 < N; r4 += 4) { /* four rows side by side: four independent chains */
+            double s[4] = {0, 0, 0, 0};
+            const int nr = N - r4 < 4 ? (int)(N - r4) : 4;
+            const float* c0 = C + (size_t)r4 * D;
+            for (int i = 0; i < D; ++i)
+                for (int u = 0; u < nr; ++u) {
+                    const double v = (double)c0[(size_t)u * D + i];
+                    s[u] = fma(v, v, s[u]);
+                }
+            for (int u = 0; u < nr; ++u) ncs[r4 + u] = s[u];
+        }
+    }
+#pragma omp parallel
+    {
+        /* the block's queries widened to fp64 once, depth-major: qd[i][u] */
+        double* qd = (double*)aligned_alloc(64, sizeof(double) * OQB * (size_t)D);
+#pragma omp for schedule(dynamic, 1)
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int b0 = blk * OQB;
+            const int nb = B - b0 < OQB ? B - b0 : OQB;
+            double nq[OQB];
+            for (int u = 0; u < OQB; ++u) {
+                const float* q = Q + (size_t)(b0 + (u < nb ? u : 0)) * D;
+                nq[u] = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    qd[(size_t)i * OQB + u] = (double)q[i];
+                    nq[u] = fma((double)q[i], (double)q[i], nq[u]);
+                }
+                if (u < nb)
+                    for (int j = 0; j < k; ++j) out_keys[(size_t)(b0 + u) * k + j] = UINT64_MAX;
+            }
+            for (int64_t r = 0; r < N; ++r) {
+                if (mask && !mask[r]) continue;
+                const float* c = C + (size_t)r * D;
+                double acc[OQB];
+                for (int u = 0; u < OQB; ++u) acc[u] = 0.0;
+                const double nc = ncs ? ncs[r] : 0.0;
+                if (space == SPACE_L2) {
+                    for (int i = 0; i < D; ++i) {
+                        const double ci = (double)c[i];
+                        const double* qi = qd + (size_t)i * OQB;
+#pragma omp simd
+                        for (int u = 0; u < OQB; ++u) {
+                            const double d = qi[u] - ci;
+                            acc[u] = fma(d, d, acc[u]);
+                        }
+                    }
+                } else {
+                    for (int i = 0; i < D; ++i) {
+                        const double ci = (double)c[i];
+                        const double* qi = qd + (size_t)i * OQB;
+#pragma omp simd
+                        for (int u = 0; u < OQB; ++u) acc[u] = fma(qi[u], ci, acc[u]);
+                    }
+                }
+                for (int u = 0; u < nb; ++u) {
+                    double d = acc[u];
+                    if (space == SPACE_IP)
+                        d = 1.0 - acc[u];
+                    else if (space == SPACE_COSINE)
+                        d = (nq[u] == 0.0 || nc == 0.0) ? 1.0 : 1.0 - acc[u] / (sqrt(nq[u]) * sqrt(nc));
+                    const uint64_t key = ((uint64_t)f32_orderable((float)d) << 32) | (uint32_t)(row_offset + r);
+                    insert_key(out_keys + (size_t)(b0 + u) * k, k, key);
+                }
+            }
+        }
+        free(qd);
+    }
+    free(ncs);
+}
+
 /* Same result, parallel over rows instead of queries (for B smaller than the core count). */
 void hrs_oracle_topk_rows(const float* Q, const float* C, int64_t N, int D, int B, int k, int space,
                           int64_t row_offset, const uint8_t* mask, uint64_t* out_keys) {

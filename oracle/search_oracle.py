@@ -12,14 +12,32 @@ PAD_KEY = np.uint64(0xFFFFFFFFFFFFFFFF)
 _lib = None
 
 
-def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+def _cpu_has(*flags):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    have = set(line.split(":", 1)[1].split())
+                    return all(x in have for x in flags)
+    except OSError:
+        pass
+    return False
+
+
+def build(force=False):
+    """liboracle.so is built with -mavx2 -mfma; a host without them gets a portable build (same results)."""
+    cmd = ["make", "-s", "-C", _HERE, "liboracle.so"]
+    if not _cpu_has("avx2", "fma"):
+        cmd = ["make", "-s", "-B", "-C", _HERE, "liboracle.so", "ARCH="]
+    elif force:
+        cmd.insert(2, "-B")
+    subprocess.check_call(cmd)
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        if not os.path.exists(_SO) or not _cpu_has("avx2", "fma"):
             build()
         L = C.CDLL(_SO)
         L.hrs_oracle_dist64.restype = C.c_double
@@ -38,7 +56,9 @@ def dist64(q, c, space="l2"):
     return lib().hrs_oracle_dist64(_p(q), _p(c), C.c_int(q.shape[0]), C.c_int(SPACES[space]))
 
 
-def topk_keys(Q, Cm, k, space="l2", row_offset=0, mask=None):
+def topk_keys(Q, Cm, k, space="l2", row_offset=0, mask=None, impl=None):
+    """impl: None picks by batch size; "plain" (one query per thread), "rows" (threads share the rows of one
+    query) and "blocked" (eight queries per pass) give bit-identical keys."""
     Q = np.ascontiguousarray(Q, np.float32)
     Cm = np.ascontiguousarray(Cm, np.float32)
     B, D = Q.shape
@@ -46,7 +66,9 @@ def topk_keys(Q, Cm, k, space="l2", row_offset=0, mask=None):
     out = np.empty((B, k), np.uint64)
     if mask is not None:
         mask = np.ascontiguousarray(mask, np.uint8)
-    fn = lib().hrs_oracle_topk if B >= 4 else lib().hrs_oracle_topk_rows
+    if impl is None:
+        impl = "blocked" if B >= 128 else ("plain" if B >= 4 else "rows")
+    fn = {"plain": lib().hrs_oracle_topk, "rows": lib().hrs_oracle_topk_rows, "blocked": lib().hrs_oracle_topk_blocked}[impl]
     fn(_p(Q), _p(Cm), C.c_int64(N), C.c_int(D), C.c_int(B), C.c_int(k), C.c_int(SPACES[space]), C.c_int64(row_offset), _p(mask), _p(out))
     return out
 

@@ -164,6 +164,40 @@ def test_mfma_scan_wide_bit_exact(eng, d, b, space, shadow):
     corpus.close()
 
 
+@pytest.mark.parametrize("b,space", [(1024, "cosine"), (640, "l2")])
+def test_mfma_scan_wide_large_batch_top100(eng, b, space):
+    """The shape of a 100M x 1024 corpus' shard query (batch 1024, top-100, bf16 shadow) at a size the oracle
+    finishes in seconds: batches of 512 and more take the one-barrier-per-tile schedule of the depth-1024 kernel
+    (eight resp. five query groups of 128), and every key equals the oracle's."""
+    rng = np.random.default_rng(1000 + b)
+    n, d, k = 120_007, 1024, 100
+    C = _unit(rng, n, d)
+    if space == "cosine":
+        C *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    Q = _unit(rng, b, d)
+    for j in range(0, 64):  # near neighbours of corpus rows, in every query group
+        qi = (j * 16) % b
+        Q[qi] = C[j * 1801] + 0.3 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+        Q[qi] /= np.linalg.norm(Q[qi])
+    C[n - 1] = C[0]
+    C[60_000] = C[0]
+    Q[b - 1] = C[0] / np.linalg.norm(C[0])
+    want = so.topk_keys(Q, C, k, space)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())  # AUTO: bf16 above depth 512
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    got = _keys(keys)
+    assert np.array_equal(got, want), f"mismatching queries: {np.nonzero((got != want).any(1))[0][:10]} stats={st}"
+    assert st["overflow_queries"] == 0 and st["fallback_queries"] <= b // 50, st
+    # the same call in two halves (what the pipelined multi-GPU step issues)
+    eng.score_topk_begin(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma")
+    _, _, keys2 = eng.score_topk_finish(want_keys=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_keys(keys2), want)
+    corpus.close()
+
+
 @pytest.mark.parametrize("shadow", ["i8", "bf16"])
 @pytest.mark.parametrize("space", ["l2", "ip", "cosine"])
 def test_mfma_awkward_rows(eng, space, shadow):
@@ -293,6 +327,22 @@ def test_keyword_counts_fuse_merge(eng):
         for j in range(k):
             assert gvn[b, j] == lookup[int(wk[b, j])]
     post.close()
+
+
+def test_keyword_counts_and_fusion_reproduce_the_reference(eng):
+    """hrs_keyword_counts + hrs_fuse_sort against the outputs of the reference's own hybrid_query
+    (scripts/chromadb_helper.py:296-325, 352-359; tests/golden/make_fusion_goldens.py): order, fused scores
+    (fp64 bit patterns) and keyword scores, case by case."""
+    import fusion_cases
+
+    for c in fusion_cases.load():
+        dev = lambda a: torch.from_numpy(a).cuda() if a.size else torch.zeros(1, dtype=torch.from_numpy(a).dtype, device="cuda")  # noqa: E731
+        post = eng.postings(torch.from_numpy(c["doc_offs"]).cuda(), dev(c["term_ids"]))
+        counts = eng.keyword_counts(post, dev(c["q_terms"]), torch.from_numpy(c["q_offs"]).cuda(), torch.from_numpy(c["rows"]).cuda())
+        comb, perm = eng.fuse_sort(torch.from_numpy(c["dist"]).cuda(), counts, torch.from_numpy(c["q_offs"]).cuda(), c["n"], c["boost"])
+        torch.cuda.synchronize()
+        fusion_cases.check(c, counts.cpu().numpy(), comb.cpu().numpy(), perm.cpu().numpy())
+        post.close()
 
 
 def test_sharded_equals_unsharded(eng):

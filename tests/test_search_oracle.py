@@ -93,3 +93,33 @@ def test_fuse_sort_matches_python_floats():
         assert [j for _, j in rows[:n]] == list(perm[b])
         assert [v for v, _ in rows[:n]] == list(comb[b])
     assert T.keyword_score("abc docker", ["docker", "zzz"]) == 0.5
+
+
+def test_fusion_and_keyword_counts_reproduce_the_reference():
+    """hrs_oracle_keyword_counts + hrs_oracle_fuse_sort against what the reference's own hybrid_query returned
+    (scripts/chromadb_helper.py:296-325, 352-359) on documents whose text spells integer term lists."""
+    import fusion_cases
+
+    cases = fusion_cases.load()
+    assert len(cases) >= 60 and any(any(c["semantic_is_int"]) for c in cases)
+    for c in cases:
+        counts = so.keyword_counts(c["doc_offs"], c["term_ids"], c["q_offs"], c["q_terms"], c["rows"])
+        comb, perm, _, _ = so.fuse_sort(c["dist"], counts, np.diff(c["q_offs"]), c["n"], c["boost"], c["nvalid"])
+        fusion_cases.check(c, counts, comb, perm)
+
+
+def test_blocked_and_plain_scans_give_identical_keys():
+    rng = np.random.default_rng(8)
+    n, d, b, k = 3001, 100, 70, 20
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((b, d)).astype(np.float32)
+    C[5] = 0
+    Q[3] = 0
+    C[100] = C[7]
+    Q[9] = C[7]
+    mask = (rng.random(n) < 0.7).astype(np.uint8)
+    for space in ("l2", "cosine", "ip"):
+        for m in (None, mask):
+            a = so.topk_keys(Q, C, k, space, row_offset=17, mask=m, impl="plain")
+            assert np.array_equal(a, so.topk_keys(Q, C, k, space, row_offset=17, mask=m, impl="blocked")), space
+            assert np.array_equal(a[:3], so.topk_keys(Q[:3], C, k, space, row_offset=17, mask=m, impl="rows")), space
