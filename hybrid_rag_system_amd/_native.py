@@ -31,6 +31,7 @@ EXPORTS = [
     "hrs_score_topk",
     "hrs_score_topk_begin",
     "hrs_score_topk_finish",
+    "hrs_score_topk_static",
     "hrs_score_stats",
     "hrs_profile_enable",
     "hrs_profile_read",
@@ -86,6 +87,7 @@ def lib():
             "hrs_score_topk": ([vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], i32),
             "hrs_score_topk_begin": ([vp, vp, vp, i32, i32, i32, vp, i32, vp], i32),
             "hrs_score_topk_finish": ([vp, vp, vp, vp, vp], i32),
+            "hrs_score_topk_static": ([vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], i32),
             "hrs_score_stats": ([vp, vp, C.POINTER(i64)], i32),
             "hrs_profile_enable": ([vp, i32], i32),
             "hrs_profile_read": ([vp, C.POINTER(dbl), C.POINTER(i64)], i32),

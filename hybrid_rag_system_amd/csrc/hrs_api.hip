@@ -96,6 +96,8 @@ extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
                       prop.gcnArchName);
         return HRS_ERR_UNSUPPORTED;
     }
+    int rc0 = hrs_exact_static_init(device);
+    if (rc0) return rc0;
     hrs_ctx* c = new hrs_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : HRS_NUM_CU;
@@ -105,7 +107,13 @@ extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
         hrs_set_error("hrs_ctx_create: hipMalloc failed: %s", hipGetErrorString(e));
         return HRS_ERR_NOMEM;
     }
-    HRS_CHECK_HIP(hipMemset(c->stats_dev, 0, 8 * sizeof(int64_t)));
+    e = hipMemset(c->stats_dev, 0, 8 * sizeof(int64_t));
+    if (e != hipSuccess) {
+        (void)hipFree(c->stats_dev);
+        delete c;
+        hrs_set_error("hrs_ctx_create: hipMemset failed: %s", hipGetErrorString(e));
+        return HRS_ERR_HIP;
+    }
     *out = c;
     return HRS_OK;
 }

@@ -292,14 +292,14 @@ __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
 }
 
 template <int SPACE, int BQ>
-static int launch_exact_t(const ExactArgs& a, int grid, hipStream_t st) {
+static int launch_exact_t(const ExactArgs& a, int grid, int device, hipStream_t st) {
     size_t lds = ENBUF * ESEG_BYTES + EQ_FLOATS * sizeof(float) + 2 * BQ * EDC * sizeof(double) +
                  BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static hrs_per_device_once attr;  // the attribute belongs to the function on ONE device
+    if (attr.need(device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr.done(device);
     }
     hipLaunchKernelGGL((k_exact_scan<SPACE, BQ>), dim3(grid), dim3(256), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
@@ -307,27 +307,24 @@ static int launch_exact_t(const ExactArgs& a, int grid, hipStream_t st) {
 }
 
 template <int SPACE>
-static int launch_exact_s(const ExactArgs& a, int grid, int bq, hipStream_t st) {
-    if (bq >= 4) return launch_exact_t<SPACE, 4>(a, grid, st);
-    if (bq >= 2) return launch_exact_t<SPACE, 2>(a, grid, st);
-    return launch_exact_t<SPACE, 1>(a, grid, st);
+static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipStream_t st) {
+    if (bq >= 4) return launch_exact_t<SPACE, 4>(a, grid, device, st);
+    if (bq >= 2) return launch_exact_t<SPACE, 2>(a, grid, device, st);
+    return launch_exact_t<SPACE, 1>(a, grid, device, st);
 }
 
 // Exact top-k of queries Q[qlist[0..nq)] (or Q[0..B) when qlist is null); nq may live on the device
 // (nq_dev), in which case B is the capacity.  Results go to keys_out[q] (q = qlist entry or index).
-int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st) {
-    if (B <= 0) return HRS_OK;
+// p0: the scratch of the call -- per-workgroup lists [B][grid][k], then the first merge level
+// [B][ceil(grid/16)][k]; every word that is read has been written by this call.
+static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
+                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, uint64_t* p0, int grid, bool timed,
+                     hipStream_t st) {
     const int64_t tiles = (c->N + ER - 1) / ER;
-    int grid = (int)(tiles < ctx->num_cu ? (tiles > 0 ? tiles : 1) : ctx->num_cu);
-    // ping-pong: partial [B][grid][k] then [B][ceil(grid/16)][k]
     const int per = 16;
     const int g1 = (grid + per - 1) / per;
-    size_t need = ((size_t)B * grid * k + (size_t)B * g1 * k) * sizeof(uint64_t);
-    int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, need);
-    if (rc) return rc;
-    uint64_t* p0 = (uint64_t*)ctx->ws_partial.ptr;
     uint64_t* p1 = p0 + (size_t)B * grid * k;
+    int rc = HRS_OK;
 
     ExactArgs a;
     a.C = c->C;
@@ -349,14 +346,14 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
         return HRS_ERR_UNSUPPORTED;
     }
     if (c->N > 0) {
-        if (!nq_dev) hrs_prof_begin(ctx, st);
+        if (timed) hrs_prof_begin(ctx, st);
         if (space == HRS_SPACE_L2)
-            rc = launch_exact_s<HRS_SPACE_L2>(a, grid, bq, st);
+            rc = launch_exact_s<HRS_SPACE_L2>(a, grid, bq, ctx->device, st);
         else if (space == HRS_SPACE_COSINE)
-            rc = launch_exact_s<HRS_SPACE_COSINE>(a, grid, bq, st);
+            rc = launch_exact_s<HRS_SPACE_COSINE>(a, grid, bq, ctx->device, st);
         else
-            rc = launch_exact_s<HRS_SPACE_IP>(a, grid, bq, st);
-        if (!nq_dev) hrs_prof_end(ctx, st);
+            rc = launch_exact_s<HRS_SPACE_IP>(a, grid, bq, ctx->device, st);
+        if (timed) hrs_prof_end(ctx, st);
         if (rc) return rc;
     } else {
         HRS_CHECK_HIP(hipMemsetAsync(p0, 0xFF, (size_t)B * grid * k * sizeof(uint64_t), st));
@@ -387,4 +384,65 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     }
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
+}
+
+static int exact_grid(const hrs_ctx* ctx, const hrs_corpus* c) {
+    const int64_t tiles = (c->N + ER - 1) / ER;
+    return (int)(tiles < ctx->num_cu ? (tiles > 0 ? tiles : 1) : ctx->num_cu);
+}
+static size_t exact_scratch_words(int B, int grid, int k) {
+    return (size_t)B * grid * k + (size_t)B * ((grid + 15) / 16) * k;
+}
+
+int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
+                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st) {
+    if (B <= 0) return HRS_OK;
+    const int grid = exact_grid(ctx, c);
+    int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, exact_scratch_words(B, grid, k) * sizeof(uint64_t));
+    if (rc) return rc;
+    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st);
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------------
+// Its scratch (what hrs_launch_exact takes from a lazily grown workspace) is a file-scope device array: every
+// GPU the library runs on holds its own copy at its own address until the process ends.  The array's name is
+// only a host-side stand-in; the address on a device comes from hipGetSymbolAddress with that device current
+// (hrs_exact_static_init, called by hrs_ctx_create) and only that pointer is ever handed to a kernel.
+#define HRS_STATIC_GRID_MAX 256
+#define HRS_STATIC_WORDS ((size_t)HRS_STATIC_MAX_B * HRS_MAX_K * (HRS_STATIC_GRID_MAX + HRS_STATIC_GRID_MAX / 16))
+static __device__ __align__(256) unsigned long long hrs_static_scratch[HRS_STATIC_WORDS];  // 4.25 MiB
+#define HRS_MAX_DEVICES 64
+static uint64_t* g_static_ptr[HRS_MAX_DEVICES];  // per device: where hrs_static_scratch lives there
+
+int hrs_exact_static_init(int device) {
+    if (device < 0 || device >= HRS_MAX_DEVICES) return HRS_OK;  // such a device simply has no static entry point
+    if (g_static_ptr[device]) return HRS_OK;
+    void* p = nullptr;
+    HRS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(hrs_static_scratch)));  // the caller made `device` current
+    g_static_ptr[device] = (uint64_t*)p;
+    return HRS_OK;
+}
+
+extern "C" int hrs_score_topk_static(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
+                                     const uint8_t* row_mask_dev, uint64_t* keys_dev, float* dist_dev,
+                                     int64_t* rows_dev, void* stream) {
+    HRS_REQUIRE(ctx && c, "hrs_score_topk_static: null handle");
+    HRS_REQUIRE(keys_dev, "hrs_score_topk_static: keys_dev is required (the library holds no result buffer here)");
+    HRS_REQUIRE(B >= 0 && (B == 0 || Q_dev), "hrs_score_topk_static: B=%d with null queries", B);
+    HRS_REQUIRE(B <= HRS_STATIC_MAX_B, "hrs_score_topk_static: B=%d exceeds the static scratch (at most %d queries per call)", B,
+                HRS_STATIC_MAX_B);
+    HRS_REQUIRE(k >= 1 && k <= HRS_MAX_K, "hrs_score_topk_static: k=%d outside [1, %d]", k, HRS_MAX_K);
+    HRS_REQUIRE(space >= 0 && space <= 2, "hrs_score_topk_static: unknown space %d", space);
+    if (B == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    const int grid = exact_grid(ctx, c);
+    uint64_t* scratch = ctx->device < HRS_MAX_DEVICES ? g_static_ptr[ctx->device] : nullptr;
+    if (!scratch || grid > HRS_STATIC_GRID_MAX || exact_scratch_words(B, grid, k) > HRS_STATIC_WORDS) {
+        hrs_set_error("hrs_score_topk_static: no static scratch for this device (device %d, %d workgroups)", ctx->device, grid);
+        return HRS_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = exact_run(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys_dev, scratch, grid, false, st);
+    if (rc == HRS_OK && (dist_dev || rows_dev)) rc = hrs_unpack_keys(ctx, keys_dev, (int64_t)B * k, dist_dev, rows_dev, stream);
+    return rc;
 }

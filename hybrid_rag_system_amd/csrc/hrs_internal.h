@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "../../include/hrs.h"
@@ -36,6 +37,16 @@ void hrs_set_error(const char* fmt, ...);
             return HRS_ERR_ARG;       \
         }                             \
     } while (0)
+
+// "Done once per device" flags for per-function attributes (hipFuncSetAttribute applies to the current device
+// only); safe when contexts of different devices are driven from different threads (doing it twice is harmless).
+struct hrs_per_device_once {
+    std::atomic<uint64_t> mask{0};
+    bool need(int device) const { return device < 0 || device >= 64 || !((mask.load(std::memory_order_acquire) >> device) & 1); }
+    void done(int device) {
+        if (device >= 0 && device < 64) mask.fetch_or(1ull << device, std::memory_order_release);
+    }
+};
 
 struct hrs_workspace {
     void* ptr = nullptr;
@@ -177,3 +188,5 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
                     uint64_t* keys_out, hipStream_t st, int phase = HRS_PHASE_ALL);
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st);
 void hrs_free_shadow(hrs_corpus* c);
+// Resolves, once per device and with that device current, where the static scratch of hrs_score_topk_static lives.
+int hrs_exact_static_init(int device);

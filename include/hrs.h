@@ -139,6 +139,21 @@ int hrs_score_topk_begin(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, i
                          const uint8_t* row_mask_dev, int mode, void* stream);
 int hrs_score_topk_finish(hrs_ctx* ctx, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev, void* stream);
 
+/* hrs_score_topk for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (one synchronous
+ * process per query, scripts/chromadb_helper.py:591-684).  Same results as hrs_score_topk in HRS_MODE_EXACT
+ * (the fp64 streaming scan), same arguments except that there is no mode and keys_dev is required; dist_dev
+ * and rows_dev stay optional.  The per-workgroup candidate lists live in a static device array of 4.25 MiB
+ * that every GPU the library runs on holds until the process ends, hence the limits: at most
+ * HRS_STATIC_MAX_B queries per call (more is HRS_ERR_ARG), devices with at most 256 compute units.  The call
+ * performs no hipMalloc / hipFree.  All calls on one GPU share that array: calls that overlap on one GPU
+ * (two streams, two threads, two contexts) race; calls on one stream are ordered and need no clearing (every
+ * word a call reads it has written itself). */
+#define HRS_STATIC_MAX_B 16
+int hrs_score_topk_static(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
+                          const uint8_t* row_mask_dev, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev,
+                          void* stream);
+
 /* Counters of the last MFMA-mode call on this ctx, valid after the stream has been waited for:
  * out[0] = queries that took the exact fallback, out[1] = largest candidate count of a query,
  * out[2] = queries whose candidate list overflowed. Waits for `stream`. */

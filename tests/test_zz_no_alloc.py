@@ -1,0 +1,78 @@
+"""hrs_score_topk_static -- the entry point that allocates no device memory -- against hrs_score_topk in
+HRS_MODE_EXACT, through the C ABI: identical keys, distances and rows, on two calls in a row (the second with
+a smaller input, so stale contents of the shared static scratch would show), with and without a row mask, and
+its argument limits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def test_static_entry_point_equals_exact_scan():
+    from hybrid_rag_system_amd import _native as N
+
+    lib = N.lib()
+    torch.cuda.set_device(0)
+    ctx = C.c_void_p()
+    N.check(lib.hrs_ctx_create(0, C.byref(ctx)), "hrs_ctx_create")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(7)
+    try:
+        # first call: the largest shape the scratch holds (16 queries, k = 128, all 256 workgroups); second:
+        # fewer rows (fewer workgroups), fewer queries, smaller k, another space, a mask
+        for n, d, b, k, space, masked in ((300_017, 384, 16, 128, 0, False), (20_011, 384, 3, 10, 1, True), (777, 100, 5, 20, 2, False)):
+            Cm = _unit(rng, n, d)
+            Cm[n // 2] = Cm[3]
+            Q = _unit(rng, b, d)
+            Q[0] = Cm[3]
+            mat, q = torch.from_numpy(Cm).cuda(), torch.from_numpy(Q).cuda()
+            mask = torch.from_numpy((rng.random(n) < 0.4).astype(np.uint8)).cuda() if masked else None
+            corpus = C.c_void_p()
+            N.check(lib.hrs_corpus_register(ctx, _p(mat), n, d, 1000, stream, C.byref(corpus)), "hrs_corpus_register")
+            want = [torch.empty((b, k), dtype=t, device="cuda") for t in (torch.int64, torch.float32, torch.int64)]
+            got = [torch.full((b, k), 7, dtype=t, device="cuda") for t in (torch.int64, torch.float32, torch.int64)]
+            N.check(lib.hrs_score_topk(ctx, corpus, _p(q), b, k, space, _p(mask), N.MODE_EXACT, _p(want[0]), _p(want[1]), _p(want[2]), stream), "hrs_score_topk")
+            torch.cuda.synchronize()
+            before = torch.cuda.memory_allocated()
+            N.check(lib.hrs_score_topk_static(ctx, corpus, _p(q), b, k, space, _p(mask), _p(got[0]), _p(got[1]), _p(got[2]), stream), "hrs_score_topk_static")
+            torch.cuda.synchronize()
+            assert torch.cuda.memory_allocated() == before
+            for w, g in zip(want, got):
+                assert torch.equal(w, g), (n, d, b, k, space)
+            if not masked:
+                assert int(got[2][0, 0]) == 1003 and abs(float(got[1][0, 0])) < 1e-6  # the planted duplicate, global row
+            # keys alone (dist / rows are optional), again on the same scratch
+            only = torch.zeros((b, k), dtype=torch.int64, device="cuda")
+            N.check(lib.hrs_score_topk_static(ctx, corpus, _p(q), b, k, space, _p(mask), _p(only), None, None, stream), "hrs_score_topk_static")
+            torch.cuda.synchronize()
+            assert torch.equal(only, want[0])
+            # limits: too many queries, no key buffer, k out of range -> HRS_ERR_ARG and a message, nothing launched
+            assert lib.hrs_score_topk_static(ctx, corpus, _p(q), 17, k, space, None, _p(only), None, None, stream) == -1
+            assert "at most 16" in N.last_error()
+            assert lib.hrs_score_topk_static(ctx, corpus, _p(q), b, k, space, None, None, None, None, stream) == -1
+            assert lib.hrs_score_topk_static(ctx, corpus, _p(q), b, 129, space, None, _p(only), None, None, stream) == -1
+            N.check(lib.hrs_corpus_release(ctx, corpus), "hrs_corpus_release")
+        # an empty corpus: every entry missing
+        corpus = C.c_void_p()
+        N.check(lib.hrs_corpus_register(ctx, None, 0, 384, 0, stream, C.byref(corpus)), "hrs_corpus_register")
+        keys = torch.zeros((2, 5), dtype=torch.int64, device="cuda")
+        rows = torch.zeros((2, 5), dtype=torch.int64, device="cuda")
+        q = torch.zeros((2, 384), device="cuda")
+        N.check(lib.hrs_score_topk_static(ctx, corpus, _p(q), 2, 5, 0, None, _p(keys), None, _p(rows), stream), "hrs_score_topk_static")
+        torch.cuda.synchronize()
+        assert (rows == -1).all() and (keys == -1).all()
+        N.check(lib.hrs_corpus_release(ctx, corpus), "hrs_corpus_release")
+    finally:
+        lib.hrs_ctx_destroy(ctx)
