@@ -26,18 +26,21 @@ EXPORTS = [
     "hrs_tokenize",
     "hrs_corpus_register",
     "hrs_corpus_release",
+    "hrs_corpus_append",
     "hrs_corpus_shadow",
     "hrs_corpus_stats",
     "hrs_score_topk",
     "hrs_score_topk_begin",
     "hrs_score_topk_finish",
     "hrs_score_topk_static",
+    "hrs_score_topk_after",
     "hrs_score_stats",
     "hrs_profile_enable",
     "hrs_profile_read",
     "hrs_encoder_load",
     "hrs_encoder_release",
     "hrs_encode",
+    "hrs_row_mask_update",
     "hrs_postings_register",
     "hrs_postings_release",
     "hrs_keyword_counts",
@@ -82,6 +85,8 @@ def lib():
             "hrs_tokenize": ([vp, C.c_char_p, vp, i32, i32, vp, vp, vp, i32], i32),
             "hrs_corpus_register": ([vp, vp, i64, i32, i64, vp, C.POINTER(vp)], i32),
             "hrs_corpus_release": ([vp, vp], i32),
+            "hrs_corpus_append": ([vp, vp, vp, i64, vp], i32),
+            "hrs_score_topk_after": ([vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),
             "hrs_corpus_shadow": ([vp, vp, i32, vp], i32),
             "hrs_corpus_stats": ([vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)], i32),
             "hrs_score_topk": ([vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], i32),
@@ -94,6 +99,7 @@ def lib():
             "hrs_encoder_load": ([vp, vp, vp, vp, C.POINTER(vp)], i32),
             "hrs_encoder_release": ([vp, vp], i32),
             "hrs_encode": ([vp, vp, vp, vp, i32, i32, vp, vp], i32),
+            "hrs_row_mask_update": ([vp, i64, vp, vp, i32, i32, vp, i32, vp, vp], i32),
             "hrs_postings_register": ([vp, vp, vp, i64, i64, C.POINTER(vp)], i32),
             "hrs_postings_release": ([vp, vp], i32),
             "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),

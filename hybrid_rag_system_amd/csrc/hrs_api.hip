@@ -1,5 +1,6 @@
 // Context, error reporting, workspaces and the entry points that only dispatch.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "hrs_internal.h"
 
@@ -101,6 +102,7 @@ extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
     hrs_ctx* c = new hrs_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : HRS_NUM_CU;
+    c->scan_qt1 = getenv("HRS_SCAN_QT1") != nullptr;
     hipError_t e = hipMalloc((void**)&c->stats_dev, 8 * sizeof(int64_t));
     if (e != hipSuccess) {
         delete c;
@@ -171,6 +173,36 @@ extern "C" int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, 
     }
     *out = c;
     return HRS_OK;
+}
+
+static int check_topk_args(const char* fn, hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space, int mode);
+
+extern "C" int hrs_corpus_append(hrs_ctx* ctx, hrs_corpus* c, const float* C_dev, int64_t N, void* stream) {
+    HRS_REQUIRE(ctx && c, "hrs_corpus_append: null handle");
+    HRS_REQUIRE(N >= c->N, "hrs_corpus_append: N=%lld is below the %lld rows registered", (long long)N, (long long)c->N);
+    HRS_REQUIRE(N == 0 || C_dev, "hrs_corpus_append: N=%lld with null matrix", (long long)N);
+    HRS_REQUIRE(N + c->row_offset < (1ll << 32), "hrs_corpus_append: rows beyond 2^32");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    return hrs_append_shadow(ctx, c, C_dev, N, (hipStream_t)stream);
+}
+
+extern "C" int hrs_score_topk_after(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
+                                    const uint8_t* row_mask_dev, const uint64_t* after_keys_dev, uint64_t* keys_dev,
+                                    float* dist_dev, int64_t* rows_dev, void* stream) {
+    int rc = check_topk_args("hrs_score_topk_after", ctx, c, Q_dev, B, k, space, HRS_MODE_EXACT);
+    if (rc) return rc;
+    HRS_REQUIRE(after_keys_dev, "hrs_score_topk_after: null after_keys_dev");
+    if (B == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    uint64_t* keys = keys_dev;
+    if (!keys) {
+        int rc0 = hrs_ws_reserve(ctx, &ctx->ws_keys, (size_t)B * k * sizeof(uint64_t));
+        if (rc0) return rc0;
+        keys = (uint64_t*)ctx->ws_keys.ptr;
+    }
+    rc = hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, (hipStream_t)stream, after_keys_dev);
+    if (rc == HRS_OK && (dist_dev || rows_dev)) rc = hrs_unpack_keys(ctx, keys, (int64_t)B * k, dist_dev, rows_dev, stream);
+    return rc;
 }
 
 extern "C" int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* c) {

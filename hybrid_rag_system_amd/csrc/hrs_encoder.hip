@@ -1098,11 +1098,11 @@ extern "C" int hrs_encoder_release(hrs_ctx* ctx, hrs_encoder* e) {
 
 template <int EPI>
 static int launch_gemm(hrs_ctx* ctx, const GemmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
+    static hrs_per_device_once attr;
     const int lds = 2 * G_STAGE_BYTES;
-    if (!attr_set) {
+    if (attr.need(ctx->device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr.done(ctx->device);
     }
     const int tiles = (g.M / G_BM) * (g.N / G_BN);
     int grid = ctx->num_cu & ~7;
@@ -1115,11 +1115,11 @@ static int launch_gemm(hrs_ctx* ctx, const GemmArgs& g, hipStream_t st) {
 
 template <int EPI>
 static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
-    static bool attr_set = false;
+    static hrs_per_device_once attr;
     const int lds = 3 * 64 * 768 + 384 * 4 + (EPI == EPI_LN ? 2 * 384 * 4 + 2 * 12 * 32 * 8 : 0);
-    if (!attr_set) {
+    if (attr.need(ctx->device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_ws<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr.done(ctx->device);
     }
     const int ngroups = g.N / 384;
     int grid = ctx->num_cu / ngroups * ngroups;
@@ -1131,11 +1131,11 @@ static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
 }
 
 static int launch_gemm_down(hrs_ctx* ctx, const GemmDownArgs& g, hipStream_t st) {
-    static bool attr_set = false;
+    static hrs_per_device_once attr;
     const int lds = 4 * 32 * 1024;
-    if (!attr_set) {
+    if (attr.need(ctx->device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_down, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr.done(ctx->device);
     }
     int grid = ctx->num_cu / 3 * 3;
     const int tiles = g.M / 32;
@@ -1241,10 +1241,7 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
             gd.bias = L.bd;
             gd.C = pre;
             gd.M = M;
-            if (l == e->cfg.layers - 1) hrs_prof_begin(ctx, st);
-            rc = launch_gemm_down(ctx, gd, st);
-            if (l == e->cfg.layers - 1) hrs_prof_end(ctx, st);
-            if (rc) return rc;
+            if ((rc = launch_gemm_down(ctx, gd, st))) return rc;
             hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, y, L.ln2g, L.ln2b, M, e->cfg.eps, x);
         } else {
             memset(&g, 0, sizeof(g));

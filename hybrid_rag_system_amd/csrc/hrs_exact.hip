@@ -41,6 +41,7 @@ struct ExactArgs {
     int nq;
     int k;
     const uint8_t* mask;
+    const uint64_t* after;  // nullable, per query: only keys strictly above it are eligible (a search resumed behind its last result)
     uint64_t* partial;  // [nq][gridDim.x][k]
     int64_t tiles;
 };
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
     uint64_t* cand = (uint64_t*)(qbuf + 2 * BQ * EDC);
     uint64_t* tau = cand + BQ * HRS_EXACT_CB;
     double* qnorm = (double*)(tau + BQ);
-    int* cnt = (int*)(qnorm + BQ);
+    uint64_t* aft = (uint64_t*)(qnorm + BQ);
+    int* cnt = (int*)(aft + BQ);
     int* qidx = cnt + BQ;
 
     const int tid = threadIdx.x;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             qidx[tid] = a.qlist ? a.qlist[j] : j;
             cnt[tid] = 0;
             tau[tid] = HRS_PAD_KEY;
+            aft[tid] = a.after ? a.after[qidx[tid]] : 0ull;
         }
         __syncthreads();
         for (int e = tid; e < BQ * D; e += 256) qf32[e] = a.Q[(size_t)qidx[e / D] * D + e % D];
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                             d = (nqv == 0.0 || ncacc == 0.0) ? 1.0 : 1.0 - acc[b] / (sqrt(nqv) * sqrt(ncacc));
                         }
                         const uint64_t key = pack_key((float)d, grow);
-                        if (key < tau[qb_i]) {
+                        if (key < tau[qb_i] && (!a.after || key > aft[qb_i])) {
                             const int pos = atomicAdd(&cnt[qb_i], 1);
                             cand[qb_i * HRS_EXACT_CB + pos] = key;  // pos < CB: cnt <= CB - ER before a tile
                         }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
 template <int SPACE, int BQ>
 static int launch_exact_t(const ExactArgs& a, int grid, int device, hipStream_t st) {
     size_t lds = ENBUF * ESEG_BYTES + EQ_FLOATS * sizeof(float) + 2 * BQ * EDC * sizeof(double) +
-                 BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
+                 BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (2 * sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
     static hrs_per_device_once attr;  // the attribute belongs to the function on ONE device
     if (attr.need(device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ>,
@@ -319,7 +322,7 @@ static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipS
 // [B][ceil(grid/16)][k]; every word that is read has been written by this call.
 static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, uint64_t* p0, int grid, bool timed,
-                     hipStream_t st) {
+                     hipStream_t st, const uint64_t* after = nullptr) {
     const int64_t tiles = (c->N + ER - 1) / ER;
     const int per = 16;
     const int g1 = (grid + per - 1) / per;
@@ -337,6 +340,7 @@ static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     a.nq = B;
     a.k = k;
     a.mask = mask;
+    a.after = after;
     a.partial = p0;
     a.tiles = tiles;
     int bq = nq_dev ? 4 : B;
@@ -395,12 +399,12 @@ static size_t exact_scratch_words(int B, int grid, int k) {
 }
 
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st) {
+                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st, const uint64_t* after) {
     if (B <= 0) return HRS_OK;
     const int grid = exact_grid(ctx, c);
     int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, exact_scratch_words(B, grid, k) * sizeof(uint64_t));
     if (rc) return rc;
-    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st);
+    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st, after);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------------

@@ -183,3 +183,39 @@ extern "C" int hrs_merge_topk(hrs_ctx* ctx, const uint64_t* keys_dev, const int3
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
+
+// Row masks of the `where` filter from per-key value codes (integer compares only).
+// t_i = codes ? ((codes[i] is one of values[0..m)) != negate) : (other[i] != 0);  mask[i] = t_i (combine 0),
+// mask[i] & t_i (1) or mask[i] | t_i (2).
+__global__ __launch_bounds__(256) void k_row_mask_update(int64_t N, const int32_t* __restrict__ codes,
+                                                         const int32_t* __restrict__ values, int m, int negate,
+                                                         const uint8_t* __restrict__ other, int combine,
+                                                         uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    bool t;
+    if (codes) {
+        const int32_t c = codes[i];
+        bool in = false;
+        for (int j = 0; j < m; ++j) in |= (values[j] == c);
+        t = in != (negate != 0);
+    } else {
+        t = other[i] != 0;
+    }
+    const bool old = combine ? mask[i] != 0 : false;
+    mask[i] = (uint8_t)(combine == 0 ? t : (combine == 1 ? (old && t) : (old || t)));
+}
+
+extern "C" int hrs_row_mask_update(hrs_ctx* ctx, int64_t N, const int32_t* codes_dev, const int32_t* values_dev, int m,
+                                   int negate, const uint8_t* other_dev, int combine, uint8_t* mask_dev, void* stream) {
+    HRS_REQUIRE(ctx && mask_dev, "hrs_row_mask_update: null argument");
+    HRS_REQUIRE(N >= 0 && m >= 0 && combine >= 0 && combine <= 2, "hrs_row_mask_update: bad size or combine %d", combine);
+    HRS_REQUIRE((codes_dev != nullptr) != (other_dev != nullptr), "hrs_row_mask_update: exactly one of codes_dev / other_dev");
+    HRS_REQUIRE(!codes_dev || m == 0 || values_dev, "hrs_row_mask_update: m=%d with null values", m);
+    if (N == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_row_mask_update, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, codes_dev,
+                       values_dev, m, negate, other_dev, combine, mask_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}

@@ -56,6 +56,7 @@ struct hrs_workspace {
 struct hrs_ctx {
     int device = 0;
     int num_cu = HRS_NUM_CU;
+    bool scan_qt1 = false;     // HRS_SCAN_QT1 in the environment at creation: one query tile per wave (tuning switch)
     hrs_workspace ws_partial;  // exact scan: per (query, workgroup) top-k keys, and merge ping-pong
     hrs_workspace ws_mfma;     // MFMA scan: bf16 queries, maxima, tau, counters, candidate lists
     hrs_workspace ws_keys;     // result keys when the caller asks only for distances / rows
@@ -89,6 +90,8 @@ struct hrs_corpus {
     int D = 0;
     int64_t row_offset = 0;
     int kind = 0;              // hrs_shadow_kind of the scan shadow
+    int want_kind = HRS_SHADOW_AUTO;  // what the caller asked for (an empty corpus has no shadow yet)
+    int64_t cap = 0;           // rows the shadow allocation holds (>= Npad); grows geometrically on append
     void* shadow = nullptr;    // owned: bf16 or int8 [Npad, Dpad], zero padded
     float2* group_pre = nullptr;   // owned (int8 shadow): per 32-row group (scale, M_g); then, in the same
     float2* group_main = nullptr;  // allocation, (1 / scale, M_g)
@@ -180,13 +183,15 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 
 // Launchers implemented in the kernel files.
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st);
+                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st,
+                     const uint64_t* after = nullptr);
 // phase: HRS_PHASE_ALL the whole call; HRS_PHASE_SCAN up to and including the main pass (B <= 1024);
 // HRS_PHASE_TAIL the rest of a call whose scan phase ran with the same arguments
 enum { HRS_PHASE_ALL = 0, HRS_PHASE_SCAN = 1, HRS_PHASE_TAIL = 2 };
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                     uint64_t* keys_out, hipStream_t st, int phase = HRS_PHASE_ALL);
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st);
+int hrs_append_shadow(hrs_ctx* ctx, hrs_corpus* c, const float* C, int64_t N_new, hipStream_t st);
 void hrs_free_shadow(hrs_corpus* c);
 // Resolves, once per device and with that device current, where the static scratch of hrs_score_topk_static lives.
 int hrs_exact_static_init(int device);

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
 // fp32 [N, D] -> bf16 [Npad, Dpad] (zero padded) and min/max squared row norm. One wave per row.
 __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ C, int64_t N, int D, int64_t Npad,
                                                       int Dpad, __bf16* __restrict__ out,
-                                                      unsigned long long* __restrict__ stats) {
+                                                      unsigned long long* __restrict__ stats, int64_t r0) {
     // 16 rows per workgroup (4 per wave): one pair of global atomics per workgroup
     __shared__ unsigned long long nmin, nmax;
     const int lane = threadIdx.x & 63;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
     __syncthreads();
     bool any = false;
     for (int j = 0; j < 4; ++j) {
-        const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + j;
+        const int64_t r = r0 + (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + j;  // r0: first row (re)built
         if (r >= Npad) break;
         double ss = 0.0;
         for (int c = lane; c < Dpad; c += 64) {
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
     }
     (void)any;
     __syncthreads();
-    if (threadIdx.x == 0 && (int64_t)blockIdx.x * 16 < N) {
+    if (threadIdx.x == 0 && r0 + (int64_t)blockIdx.x * 16 < N) {
         atomicMin(&stats[0], nmin);
         atomicMax(&stats[1], nmax);
     }
@@ -582,12 +582,12 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict__ C, int64_t N, int D, int Dpad,
                                                          int8_t* __restrict__ out, float2* __restrict__ pre_pair,
                                                          float2* __restrict__ main_pair,
-                                                         unsigned long long* __restrict__ stats) {
+                                                         unsigned long long* __restrict__ stats, int64_t g0) {
     __shared__ float red[4];
     __shared__ int l1max;
     __shared__ unsigned long long nmin, nmax;  // squared norms as bit patterns (non-negative doubles order like them)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t g = blockIdx.x, r0 = g * 32;
+    const int64_t g = g0 + blockIdx.x, r0 = g * 32;  // g0: first group (re)built
     if (threadIdx.x == 0) {
         l1max = 0;
         nmin = ~0ull;
@@ -650,6 +650,38 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
     }
 }
 
+// min/max squared row norm of a corpus that has no shadow (the shadow builders compute them on the way).
+// One wave per row, 16 rows per workgroup, one pair of global atomics per workgroup.
+__global__ __launch_bounds__(256) void k_row_norm_stats(const float* __restrict__ C, int64_t N, int D,
+                                                        unsigned long long* __restrict__ stats, int64_t r0) {
+    __shared__ unsigned long long nmin, nmax;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        nmin = ~0ull;
+        nmax = 0ull;
+    }
+    __syncthreads();
+    for (int j = 0; j < 4; ++j) {
+        const int64_t r = r0 + (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + j;
+        if (r >= N) break;
+        double ss = 0.0;
+        for (int c = lane; c < D; c += 64) {
+            const float v = C[r * D + c];
+            ss += (double)v * (double)v;
+        }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) {
+            atomicMin(&nmin, (unsigned long long)__double_as_longlong(ss));
+            atomicMax(&nmax, (unsigned long long)__double_as_longlong(ss));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && r0 + (int64_t)blockIdx.x * 16 < N) {
+        atomicMin(&stats[0], nmin);
+        atomicMax(&stats[1], nmax);
+    }
+}
+
 __global__ void k_init_stats(unsigned long long* stats) {
     stats[0] = (unsigned long long)__double_as_longlong(1e300);
     stats[1] = 0ull;
@@ -663,44 +695,118 @@ void hrs_free_shadow(hrs_corpus* c) {
     c->group_pre = c->group_main = nullptr;
     c->norm_stats = nullptr;
     c->kind = HRS_SHADOW_NONE;
+    c->cap = 0;
+}
+
+static int64_t shadow_npad(int64_t N) { return (N + 63) / 64 * 64 + 64; }  // one spare tile: clamped prefetches stay in bounds
+
+// Allocates shadow storage for `cap` rows (a multiple of 64) of the corpus' kind / Dpad.
+static int shadow_alloc(const hrs_corpus* c, int64_t cap, void** shadow, float2** group_pre) {
+    const size_t esz = c->kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
+    *shadow = nullptr;
+    *group_pre = nullptr;
+    hipError_t e = hipMalloc(shadow, (size_t)cap * c->Dpad * esz);
+    if (e == hipSuccess && c->kind == HRS_SHADOW_I8) e = hipMalloc((void**)group_pre, (size_t)(2 * (cap / 32) + 64) * sizeof(float2));
+    if (e != hipSuccess) {
+        if (*shadow) (void)hipFree(*shadow);
+        *shadow = nullptr;
+        hrs_set_error("corpus shadow allocation of %lld rows failed: %s", (long long)cap, hipGetErrorString(e));
+        return HRS_ERR_NOMEM;
+    }
+    return HRS_OK;
+}
+
+// Quantises rows [r_from, Npad) of the corpus into the shadow (r_from a multiple of 32) and folds their norms
+// into the statistics.
+static int shadow_fill(hrs_corpus* c, int64_t r_from, hipStream_t st) {
+    if (c->kind == HRS_SHADOW_I8) {
+        const int64_t g0 = r_from / 32, groups = c->Npad / 32;
+        hipLaunchKernelGGL(k_build_shadow_i8, dim3((unsigned)(groups - g0)), dim3(256), 0, st, c->C, c->N, c->D, c->Dpad,
+                           (int8_t*)c->shadow, c->group_pre, c->group_main, (unsigned long long*)c->norm_stats, g0);
+    } else {
+        hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)((c->Npad - r_from + 15) / 16)), dim3(256), 0, st, c->C, c->N, c->D,
+                           c->Npad, c->Dpad, (__bf16*)c->shadow, (unsigned long long*)c->norm_stats, r_from);
+    }
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
 }
 
 // (Re)build the scan shadow of a corpus: int8 with group scales (default) or bf16.
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st) {
     (void)ctx;
     hrs_free_shadow(c);
+    c->want_kind = kind;
     if (kind == HRS_SHADOW_AUTO) kind = c->D <= 512 ? HRS_SHADOW_I8 : HRS_SHADOW_BF16;
-    c->Npad = (c->N + 63) / 64 * 64 + 64;  // one spare tile: clamped prefetches stay in bounds
-    if (c->N == 0 || kind == HRS_SHADOW_NONE) return HRS_OK;
+    c->Npad = shadow_npad(c->N);
+    if (c->N == 0) return HRS_OK;
+    hipError_t e = hipMalloc((void**)&c->norm_stats, 2 * sizeof(double));
+    if (e != hipSuccess) {
+        hrs_set_error("corpus statistics allocation failed: %s", hipGetErrorString(e));
+        return HRS_ERR_NOMEM;
+    }
+    hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(1), 0, st, (unsigned long long*)c->norm_stats);
+    if (kind == HRS_SHADOW_NONE || c->D > 1024) {  // no shadow (deeper rows: exact scan only); the row norms all the same
+        hipLaunchKernelGGL(k_row_norm_stats, dim3((unsigned)((c->N + 15) / 16)), dim3(256), 0, st, c->C, c->N, c->D,
+                           (unsigned long long*)c->norm_stats, (int64_t)0);
+        HRS_CHECK_HIP(hipGetLastError());
+        return HRS_OK;
+    }
     c->Dpad = (c->D + 127) / 128 * 128;
     if (kind == HRS_SHADOW_I8) {
         if (c->Dpad > 512) c->Dpad = c->Dpad <= 768 ? 768 : 1024;
     } else {
         if (c->Dpad > 512 && c->Dpad < 1024) c->Dpad = 1024;  // one wide kernel covers (512, 1024]
     }
-    if (c->D > 1024) return HRS_OK;  // deeper rows: exact scan only
-    const size_t esz = kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
-    const int64_t groups = c->Npad / 32;
-    hipError_t e = hipMalloc((void**)&c->norm_stats, 2 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->shadow, (size_t)c->Npad * c->Dpad * esz);
-    if (e == hipSuccess && kind == HRS_SHADOW_I8) e = hipMalloc((void**)&c->group_pre, (size_t)(2 * groups + 64) * sizeof(float2));
-    if (e != hipSuccess) {
-        hrs_set_error("corpus shadow allocation failed: %s", hipGetErrorString(e));
-        hrs_free_shadow(c);
-        return HRS_ERR_NOMEM;
-    }
-    hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(1), 0, st, (unsigned long long*)c->norm_stats);
-    if (kind == HRS_SHADOW_I8) {
-        c->group_main = c->group_pre + groups + 32;
-        hipLaunchKernelGGL(k_build_shadow_i8, dim3((unsigned)groups), dim3(256), 0, st, c->C, c->N, c->D, c->Dpad,
-                           (int8_t*)c->shadow, c->group_pre, c->group_main, (unsigned long long*)c->norm_stats);
-    } else {
-        hipLaunchKernelGGL(k_build_shadow, dim3((unsigned)((c->Npad + 15) / 16)), dim3(256), 0, st, c->C, c->N, c->D,
-                           c->Npad, c->Dpad, (__bf16*)c->shadow, (unsigned long long*)c->norm_stats);
-    }
-    HRS_CHECK_HIP(hipGetLastError());
     c->kind = kind;
-    return HRS_OK;
+    int rc = shadow_alloc(c, c->Npad, &c->shadow, &c->group_pre);
+    if (rc) {
+        hrs_free_shadow(c);
+        return rc;
+    }
+    c->cap = c->Npad;
+    if (kind == HRS_SHADOW_I8) c->group_main = c->group_pre + c->cap / 32 + 32;
+    return shadow_fill(c, 0, st);
+}
+
+// The corpus grew to N_new rows at C (the first c->N rows unchanged, possibly at a new address): only the new
+// rows -- and the last, partly filled 32-row group, whose int8 scale may change -- are quantised.  The shadow's
+// allocation doubles when it is full, so a long run of small appends costs O(rows appended) in total.
+int hrs_append_shadow(hrs_ctx* ctx, hrs_corpus* c, const float* C, int64_t N_new, hipStream_t st) {
+    const int64_t N_old = c->N;
+    c->C = C;
+    c->N = N_new;
+    if (N_new == N_old) return HRS_OK;
+    if (N_old == 0 || (!c->shadow && !c->norm_stats)) return hrs_build_shadow(ctx, c, c->want_kind, st);
+    c->Npad = shadow_npad(N_new);
+    if (!c->shadow) {  // no shadow by choice or depth: the statistics alone
+        hipLaunchKernelGGL(k_row_norm_stats, dim3((unsigned)((N_new - N_old + 15) / 16)), dim3(256), 0, st, c->C, c->N, c->D,
+                           (unsigned long long*)c->norm_stats, N_old);
+        HRS_CHECK_HIP(hipGetLastError());
+        return HRS_OK;
+    }
+    const int64_t r_from = N_old / 32 * 32;
+    if (c->Npad > c->cap) {
+        int64_t cap = c->cap * 2;
+        if (cap < c->Npad) cap = c->Npad;
+        void* ns = nullptr;
+        float2* ng = nullptr;
+        int rc = shadow_alloc(c, cap, &ns, &ng);
+        if (rc) return rc;
+        const size_t esz = c->kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
+        HRS_CHECK_HIP(hipMemcpyAsync(ns, c->shadow, (size_t)r_from * c->Dpad * esz, hipMemcpyDeviceToDevice, st));
+        if (ng) {
+            HRS_CHECK_HIP(hipMemcpyAsync(ng, c->group_pre, (size_t)(r_from / 32) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            HRS_CHECK_HIP(hipMemcpyAsync(ng + cap / 32 + 32, c->group_main, (size_t)(r_from / 32) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
+        HRS_CHECK_HIP(hipStreamSynchronize(st));  // the copies are done (and so is whatever read the old shadow on st)
+        (void)hipFree(c->shadow);
+        if (c->group_pre) (void)hipFree(c->group_pre);
+        c->shadow = ns;
+        c->group_pre = ng;
+        c->group_main = ng ? ng + cap / 32 + 32 : nullptr;
+        c->cap = cap;
+    }
+    return shadow_fill(c, r_from, st);
 }
 
 // The few control words a call starts from zero (queue lengths, statistics) are cleared by the first
@@ -1079,14 +1185,14 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
 }
 
 template <int KS, int TR, bool I8, int QT>
-static int launch_scan_qt(const MfmaArgs& a, int mode, hipStream_t st) {
+static int launch_scan_qt(const MfmaArgs& a, int mode, int device, hipStream_t st) {
     const size_t lds = (size_t)scan_nbuf(TR * KS * 32, QT) * TR * KS * 32;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static hrs_per_device_once attr;
+    if (attr.need(device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 0, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 1, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 2, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr.done(device);
     }
     if (mode == 1)
         hipLaunchKernelGGL((k_mfma_scan<KS, TR, 1, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
@@ -1104,21 +1210,21 @@ template <int KS, bool I8>
 constexpr int scan_qt_max() { return (I8 && KS <= 12) ? 2 : 1; }
 
 template <int KS, int TR, bool I8>
-static int launch_scan(MfmaArgs a, int mode, int qt, const hrs_corpus* c, hipStream_t st) {
+static int launch_scan(MfmaArgs a, int mode, int qt, const hrs_corpus* c, int device, hipStream_t st) {
     a.group = mode == 0 ? c->group_main : c->group_pre;
-    if (qt == 2 && scan_qt_max<KS, I8>() == 2) return launch_scan_qt<KS, TR, I8, scan_qt_max<KS, I8>()>(a, mode, st);
-    return launch_scan_qt<KS, TR, I8, 1>(a, mode, st);
+    if (qt == 2 && scan_qt_max<KS, I8>() == 2) return launch_scan_qt<KS, TR, I8, scan_qt_max<KS, I8>()>(a, mode, device, st);
+    return launch_scan_qt<KS, TR, I8, 1>(a, mode, device, st);
 }
 
 template <int SPACE>
-static int launch_select(const SelectArgs& s, int bc, hipStream_t st) {
+static int launch_select(const SelectArgs& s, int bc, int device, hipStream_t st) {
     const int lds_small = (HRS_CAND_CAP + HRS_RESCORE_MAX) * 8 + 1024 * 4 + 4 * 64 * 144;
     const int lds_big = (HRS_CAND_CAP_BIG + 4096) * 8 + 1024 * 4 + 4 * 64 * 144;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static hrs_per_device_once attr;
+    if (attr.need(device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_select_rescore<SPACE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_select_rescore<SPACE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
-        attr_set = true;
+        attr.done(device);
     }
     hipLaunchKernelGGL((k_select_rescore<SPACE, false>), dim3(bc), dim3(256), lds_small, st, s);
     // deferred queries (device-side count; workgroups beyond it leave at once)
@@ -1188,7 +1294,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         const int bc = B - qbase < BC ? B - qbase : BC;
         const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
         // 64 queries per wave for large batches on the shallow int8 kernels
-        const int qt = (i8 && KS <= 12 && bpad >= 512 && !getenv("HRS_SCAN_QT1")) ? 2 : 1;
+        const int qt = (i8 && KS <= 12 && bpad >= 512 && !ctx->scan_qt1) ? 2 : 1;
         const int nqg = bpad / (wide ? 128 : MF_QPB * qt);
         const int nslices = HRS_NUM_CU / nqg;
         // cleared by the convert kernel: this chunk's deferred-queue length; for the first chunk also the
@@ -1262,7 +1368,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         };
 #define HRS_SCAN(KS_, TR_, I8_)                                                                      \
     case KS_: {                                                                                      \
-        auto scan = [&](int mode) { return launch_scan<KS_, TR_, I8_>(a, mode, qt, c, st); };        \
+        auto scan = [&](int mode) { return launch_scan<KS_, TR_, I8_>(a, mode, qt, c, ctx->device, st); };        \
         if ((rc = tau_steps(scan))) return rc;                                                       \
         hrs_prof_begin(ctx, st);                                                                     \
         rc = scan(0);                                                                                \
@@ -1271,13 +1377,13 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     } break;
         if (!do_scan) {
         } else if (wide) {
-            static bool attr_set = false;
+            static hrs_per_device_once attr;
             const int lds = 4 * 32 * 1024;
-            if (!attr_set) {
+            if (attr.need(ctx->device)) {
                 HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                attr_set = true;
+                attr.done(ctx->device);
             }
             auto scan = [&](int mode) {
                 if (mode == 1)
@@ -1342,11 +1448,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.qlist2 = (int32_t*)(ws + o_q2) + 64;
         s.nflag2 = (int32_t*)(ws + o_q2);
         if (space == HRS_SPACE_L2)
-            rc = launch_select<HRS_SPACE_L2>(s, bc, st);
+            rc = launch_select<HRS_SPACE_L2>(s, bc, ctx->device, st);
         else if (space == HRS_SPACE_COSINE)
-            rc = launch_select<HRS_SPACE_COSINE>(s, bc, st);
+            rc = launch_select<HRS_SPACE_COSINE>(s, bc, ctx->device, st);
         else
-            rc = launch_select<HRS_SPACE_IP>(s, bc, st);
+            rc = launch_select<HRS_SPACE_IP>(s, bc, ctx->device, st);
         if (rc) return rc;
         HRS_CHECK_HIP(hipGetLastError());
     }

@@ -15,6 +15,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <exception>
+
 #include "hrs_internal.h"
 #include "hrs_unicode_tables.h"
 
@@ -250,7 +252,9 @@ extern "C" int hrs_tokenizer_create(const char* vocab_utf8, int64_t vocab_bytes,
                                     hrs_tokenizer** out) {
     HRS_REQUIRE(out, "hrs_tokenizer_create: null out");
     HRS_REQUIRE(max_len >= 2 && max_len <= 512, "hrs_tokenizer_create: max_len=%d outside [2, 512]", max_len);
-    hrs_tokenizer* t = new hrs_tokenizer();
+    hrs_tokenizer* t = nullptr;
+    try {  // no C++ exception crosses the C boundary
+    t = new hrs_tokenizer();
     t->lower = lower != 0;
     t->max_len = max_len;
     if (vocab_utf8 && vocab_bytes > 0) {
@@ -281,8 +285,17 @@ extern "C" int hrs_tokenizer_create(const char* vocab_utf8, int64_t vocab_bytes,
         }
         need("[PAD]", &t->pad_id, false);
     } else {
-        HRS_REQUIRE(hash_vocab_size > 1000, "hrs_tokenizer_create: hash vocabulary of %d ids", hash_vocab_size);
+        if (hash_vocab_size <= 1000) {
+            delete t;
+            hrs_set_error("hrs_tokenizer_create: hash vocabulary of %d ids", hash_vocab_size);
+            return HRS_ERR_ARG;
+        }
         t->hash_vocab = hash_vocab_size;
+    }
+    } catch (const std::exception& ex) {
+        delete t;
+        hrs_set_error("hrs_tokenizer_create: %s", ex.what());
+        return HRS_ERR_NOMEM;
     }
     *out = t;
     return HRS_OK;
@@ -301,7 +314,9 @@ extern "C" int hrs_tokenize(hrs_tokenizer* t, const char* texts, const int64_t* 
     if (threads > 64) threads = 64;
     if (threads > B) threads = B > 0 ? B : 1;
     std::atomic<int> next(0);
+    std::atomic<bool> failed(false);
     auto work = [&]() {
+        try {  // an exception (out of host memory) must neither leave a thread nor cross the C boundary
         std::vector<int32_t> row;
         for (;;) {
             const int b = next.fetch_add(1);
@@ -314,13 +329,24 @@ extern "C" int hrs_tokenize(hrs_tokenizer* t, const char* texts, const int64_t* 
             for (int j = n; j < row_stride; ++j) dst[j] = t->pad_id;
             lens[b] = n;
         }
+        } catch (...) {
+            failed = true;
+        }
     };
     if (threads == 1) {
         work();
     } else {
         std::vector<std::thread> pool;
-        for (int i = 0; i < threads; ++i) pool.emplace_back(work);
+        try {
+            for (int i = 0; i < threads; ++i) pool.emplace_back(work);
+        } catch (...) {  // fewer threads than asked for: the ones that started share the texts with this one
+            work();
+        }
         for (auto& th : pool) th.join();
+    }
+    if (failed) {
+        hrs_set_error("hrs_tokenize: out of host memory");
+        return HRS_ERR_NOMEM;
     }
     return HRS_OK;
 }

@@ -22,12 +22,16 @@ def _stream():
 class Corpus:
     """The embedding matrix of one shard, registered with the engine (keeps `matrix` alive)."""
 
-    def __init__(self, engine, matrix, row_offset=0, shadow="auto"):
+    def __init__(self, engine, matrix, row_offset=0, shadow="auto", n=None):
         if not (matrix.is_cuda and matrix.dtype == torch.float32 and matrix.dim() == 2 and matrix.is_contiguous()):
             raise ValueError("corpus must be a contiguous fp32 [N, D] CUDA tensor")
         self.engine = engine
         self.matrix = matrix
         self.n, self.dim = matrix.shape
+        if n is not None:  # the first n rows of a buffer that has room for more (see append)
+            if not 0 <= n <= matrix.shape[0]:
+                raise ValueError(f"n={n} outside the matrix ({matrix.shape[0]} rows)")
+            self.n = int(n)
         self.row_offset = int(row_offset)
         h = C.c_void_p()
         N.check(
@@ -37,6 +41,17 @@ class Corpus:
         self._h = h
         if shadow != "auto":
             self.set_shadow(shadow)
+
+    def append(self, matrix, n=None):
+        """The collection grew: `matrix` (fp32 [>= n, D], contiguous; rows [0, self.n) as registered, possibly at a
+        new address) now holds n rows.  Only the new rows are quantised (hrs_corpus_append)."""
+        n = matrix.shape[0] if n is None else int(n)
+        if not (matrix.is_cuda and matrix.dtype == torch.float32 and matrix.dim() == 2 and matrix.is_contiguous() and matrix.shape[1] == self.dim):
+            raise ValueError("corpus must stay a contiguous fp32 [N, D] CUDA tensor of the registered depth")
+        if n > matrix.shape[0] or n < self.n:
+            raise ValueError(f"append to {n} rows: the matrix holds {matrix.shape[0]}, the corpus {self.n}")
+        N.check(N.lib().hrs_corpus_append(self.engine._ctx, self._h, _ptr(matrix) if n else None, n, _stream()), "hrs_corpus_append")
+        self.matrix, self.n = matrix, n
 
     def set_shadow(self, kind):
         """Rebuild the scan shadow: "auto" (int8 up to depth 512, else bf16), "i8", "bf16" or "none" (exact scan only)."""
@@ -150,8 +165,8 @@ class Engine:
         """Scans launched through this engine wait for the last scan launched through `other` (see HybridPipeline)."""
         N.check(N.lib().hrs_ctx_set_peer(self._ctx, other._ctx if other is not None else None), "hrs_ctx_set_peer")
 
-    def corpus(self, matrix, row_offset=0, shadow="auto"):
-        return Corpus(self, matrix, row_offset, shadow)
+    def corpus(self, matrix, row_offset=0, shadow="auto", n=None):
+        return Corpus(self, matrix, row_offset, shadow, n)
 
     def postings(self, doc_offs, term_ids, row_offset=0):
         return Postings(self, doc_offs, term_ids, row_offset)
@@ -176,6 +191,19 @@ class Engine:
             "hrs_score_topk",
         )
         return (dist, rows, keys) if want_keys else (dist, rows)
+
+    def score_topk_after(self, corpus, queries, k, after_keys, space="l2", mask=None):
+        """score_topk resumed behind `after_keys` (int64 [B], uint64 bits: the last key each query has received)
+        -> (dist, rows, keys)."""
+        B = queries.shape[0]
+        dist = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        rows = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        keys = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        N.check(
+            N.lib().hrs_score_topk_after(self._ctx, corpus._h, _ptr(queries), B, k, N.SPACES[space], _ptr(mask), _ptr(after_keys), _ptr(keys), _ptr(dist), _ptr(rows), _stream()),
+            "hrs_score_topk_after",
+        )
+        return dist, rows, keys
 
     def score_topk_begin(self, corpus, queries, k, space="l2", mask=None, mode="auto"):
         """First half of score_topk (the scan); `queries` and `mask` must stay alive until score_topk_finish."""
@@ -215,6 +243,15 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         N.check(N.lib().hrs_profile_read(self._ctx, C.byref(ms), C.byref(n)), "hrs_profile_read")
         return ms.value, n.value
+
+    def row_mask_update(self, mask, codes=None, values=None, negate=False, other=None, combine="set"):
+        """mask uint8 [N] <- combine(mask, codes in values (xor negate))  or  combine(mask, other); see hrs_row_mask_update."""
+        m = values.numel() if values is not None else 0
+        N.check(
+            N.lib().hrs_row_mask_update(self._ctx, mask.numel(), _ptr(codes), _ptr(values), m, int(bool(negate)), _ptr(other), {"set": 0, "and": 1, "or": 2}[combine], _ptr(mask), _stream()),
+            "hrs_row_mask_update",
+        )
+        return mask
 
     def keyword_counts(self, postings, q_terms, q_term_offs, cand_rows):
         B, c = cand_rows.shape

@@ -41,6 +41,8 @@ class _Conn:
 
 def dispatch(client, req, embed=None):
     """One request against a store.Client-like object -> the JSON-able result."""
+    if not isinstance(req, dict):
+        raise ValueError("a request is a JSON object")
     op = req.get("op")
     if op == "ping":
         return {"pid": os.getpid(), "collections": [c.name for c in client.list_collections()]}
@@ -79,7 +81,11 @@ def serve(client, address, embed=None, ready=None):
     if os.path.exists(address):
         os.unlink(address)
     lsock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-    lsock.bind(address)
+    old_umask = os.umask(0o177)  # the socket is created 0600: nobody else can connect, not even before the chmod
+    try:
+        lsock.bind(address)
+    finally:
+        os.umask(old_umask)
     os.chmod(address, 0o600)
     lsock.listen(64)
     lsock.setblocking(False)
@@ -114,7 +120,7 @@ def serve(client, address, embed=None, ready=None):
                         raise ConnectionError("closed")
                     conn.buf += part
                     for req in conn.messages():
-                        if req.get("op") == "shutdown":
+                        if isinstance(req, dict) and req.get("op") == "shutdown":
                             reply(conn.sock, {"ok": True, "result": None})
                             stop["now"] = True
                             break
@@ -123,7 +129,7 @@ def serve(client, address, embed=None, ready=None):
                         except Exception as e:  # reported to the caller, who raises it again
                             out = {"ok": False, "error": str(e), "type": type(e).__name__}
                         reply(conn.sock, out)
-                except (ConnectionError, OSError, ValueError):
+                except Exception:  # whatever one client does wrong costs that client its connection, not the server
                     sel.unregister(conn.sock)
                     conn.sock.close()
     finally:

@@ -8,8 +8,11 @@ live in HBM and every distance / top-k comes from libhrs.so.  Persistence is a d
 collection (fp32 embeddings + json lines), because there is no server to keep state between the
 `index` and `query` invocations of the CLI.
 """
+import contextlib
+import fcntl
 import json
 import os
+import re
 
 import numpy as np
 import torch
@@ -115,7 +118,26 @@ def _match(meta, where):
     return True
 
 
+_NAME_RE = re.compile(r"^[A-Za-z0-9][A-Za-z0-9._-]{1,61}[A-Za-z0-9]$")
+
+
+def validate_name(name):
+    """ChromaDB's collection-name rule: 3-63 characters from [A-Za-z0-9._-], first and last alphanumeric, no "..".
+    The name becomes a directory under the data directory, so nothing else may pass (no separators, no "..")."""
+    if not isinstance(name, str) or not _NAME_RE.match(name) or ".." in name:
+        raise ValueError(f"invalid collection name {name!r}: expected 3-63 characters from [A-Za-z0-9._-], starting and ending with a letter or digit, without '..'")
+    return name
+
+
+_DEVICE_OPS = ("$eq", "$ne", "$in", "$nin")
+
+
 class Collection:
+    """One collection: ids / documents / metadatas on the host, embeddings on the host (for persistence and peek)
+    and in HBM (for every query).  Appends are incremental end to end: the files grow by the new rows, the device
+    matrix and its scan shadow grow geometrically (hrs_corpus_append quantises only the new rows), the per-key
+    metadata codes behind `where` masks are extended, never rebuilt."""
+
     def __init__(self, client, name, embedding_function=None, metadata=None, space="l2"):
         self._client = client
         self.name = name
@@ -124,47 +146,133 @@ class Collection:
         self.space = space
         self.ids, self.documents, self.metadatas = [], [], []
         self._index = {}
-        self._emb = np.zeros((0, 0), np.float32)
-        self._corpus = None
-        self._dev = None
-        self._load()
+        self._buf = np.zeros((0, 0), np.float32)  # host rows, capacity doubles; self._emb is the filled part
+        self._emb = self._buf
+        self._rows_bytes = 0   # committed length of rows.jsonl that has been read / written by this object
+        self._corpus = None    # engine.Corpus over self._dev[: self._dev_rows]
+        self._dev = None       # device rows, capacity doubles
+        self._dev_rows = 0
+        self._codes = {}       # metadata key -> {"map": value -> code, "host": [code per row], "dev": int32 tensor, "n": rows on the device}
+        with self._locked():
+            self._sync_from_disk()
 
     # ---- persistence ---------------------------------------------------------------------------
+    # Layout: <dir>/rows.jsonl (one {"id", "document", "metadata"} per line), <dir>/embeddings.f32 (row-major
+    # fp32), <dir>/meta.json (the COMMIT record: count, dim, rows_bytes), <dir>/.lock (flock).  A writer appends
+    # to the two data files, fsyncs, then replaces meta.json atomically; whatever lies beyond the committed
+    # lengths is the tail of a writer that died and is cut off by the next one.  The reference leaves all of this
+    # to the ChromaDB server, which serialises its writers (scripts/chromadb_helper.py:74-86).
     def _dir(self):
         return os.path.join(self._client.path, self.name) if self._client.path else None
 
-    def _load(self):
+    @contextlib.contextmanager
+    def _locked(self):
         d = self._dir()
-        if not d or not os.path.exists(os.path.join(d, "meta.json")):
+        if not d or not os.path.isdir(d):  # nothing on disk yet: nothing to guard (add() creates the directory first)
+            yield
             return
-        with open(os.path.join(d, "meta.json")) as f:
-            meta = json.load(f)
-        self.metadata = meta.get("metadata", self.metadata)
-        self.space = meta.get("space", self.space)
-        with open(os.path.join(d, "rows.jsonl")) as f:
-            for line in f:
-                r = json.loads(line)
-                self.ids.append(r["id"])
-                self.documents.append(r["document"])
-                self.metadatas.append(r["metadata"])
-        self._index = {i: n for n, i in enumerate(self.ids)}
-        dim = meta["dim"]
-        self._emb = np.fromfile(os.path.join(d, "embeddings.f32"), np.float32).reshape(-1, dim) if dim else self._emb
-        if len(self.ids) != self._emb.shape[0]:
-            raise RuntimeError(f"collection {self.name}: {len(self.ids)} rows but {self._emb.shape[0]} embeddings on disk")
+        fd = os.open(os.path.join(d, ".lock"), os.O_CREAT | os.O_RDWR, 0o600)
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX)
+            yield
+        finally:
+            fcntl.flock(fd, fcntl.LOCK_UN)
+            os.close(fd)
+
+    def _read_meta(self):
+        d = self._dir()
+        path = os.path.join(d, "meta.json") if d else None
+        if not path or not os.path.exists(path):
+            return None
+        with open(path) as f:
+            return json.load(f)
+
+    def _sync_from_disk(self):
+        """Under the lock: take in the rows other processes have committed since this object last looked, and cut
+        off any uncommitted tail."""
+        meta = self._read_meta()
+        if meta is None:
+            return
+        d = self._dir()
+        if not self.ids:
+            self.metadata = meta.get("metadata", self.metadata)
+            self.space = meta.get("space", self.space)
+        count, dim = int(meta["count"]), int(meta["dim"])
+        rows_path, emb_path = os.path.join(d, "rows.jsonl"), os.path.join(d, "embeddings.f32")
+        have = len(self.ids)
+        if count < have:
+            raise RuntimeError(f"collection {self.name}: {count} rows committed on disk but {have} loaded (files replaced underneath?)")
+        rows_bytes = meta.get("rows_bytes")
+        with open(rows_path, "rb") as f:
+            f.seek(self._rows_bytes)
+            if rows_bytes is None:  # written before the commit record held it: count lines
+                lines = []
+                for _ in range(count - have):
+                    line = f.readline()
+                    if not line.endswith(b"\n"):
+                        break
+                    lines.append(line)
+                rows_bytes = self._rows_bytes + sum(len(x) for x in lines)
+            else:
+                blob = f.read(int(rows_bytes) - self._rows_bytes)
+                lines = blob.splitlines(keepends=True)
+        if len(lines) != count - have or (lines and not lines[-1].endswith(b"\n")):
+            raise RuntimeError(f"collection {self.name}: rows.jsonl holds {have + len(lines)} of the {count} committed rows")
+        emb_bytes = count * dim * 4
+        if os.path.getsize(emb_path) < emb_bytes:
+            raise RuntimeError(f"collection {self.name}: embeddings.f32 holds fewer than the {count} committed rows")
+        for path, size in ((rows_path, int(rows_bytes)), (emb_path, emb_bytes)):
+            if os.path.getsize(path) > size:  # the tail of a writer that died before its commit
+                with open(path, "r+b") as f:
+                    f.truncate(size)
+        if count > have:
+            new = np.fromfile(emb_path, np.float32, count=(count - have) * dim, offset=have * dim * 4).reshape(-1, dim)
+            recs = [json.loads(x) for x in lines]
+            self._take_rows([r["id"] for r in recs], [r["document"] for r in recs], [r["metadata"] for r in recs], new)
+        self._rows_bytes = int(rows_bytes)
+
+    def _take_rows(self, ids, documents, metadatas, emb):
+        """Append rows to the host-side state (not to disk, not yet to the device)."""
+        first = len(self.ids)
+        if self._buf.shape[1] != emb.shape[1]:
+            if first:
+                raise ValueError(f"embedding dimension {emb.shape[1]} != collection dimension {self._buf.shape[1]}")
+            self._buf = np.empty((0, emb.shape[1]), np.float32)
+        need = first + emb.shape[0]
+        if self._buf.shape[0] < need:  # rows live in a buffer that doubles, so a long run of small adds stays linear
+            nb = np.empty((max(need, 2 * self._buf.shape[0], 1024), emb.shape[1]), np.float32)
+            nb[:first] = self._buf[:first]
+            self._buf = nb
+        self._buf[first:need] = emb
+        self._emb = self._buf[:need]
+        for i, doc, meta in zip(ids, documents, metadatas):
+            self._index[i] = len(self.ids)
+            self.ids.append(i)
+            self.documents.append(doc)
+            self.metadatas.append(meta)
+        for key, st in self._codes.items():  # extend the cached where-codes by the new rows
+            st["host"].extend(self._code_of(st, (m or {}).get(key)) for m in metadatas)
 
     def _append_to_disk(self, first):
         d = self._dir()
         if not d:
             return
-        os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "rows.jsonl"), "a") as f:
-            for n in range(first, len(self.ids)):
-                f.write(json.dumps({"id": self.ids[n], "document": self.documents[n], "metadata": self.metadatas[n]}) + "\n")
+        with open(os.path.join(d, "rows.jsonl"), "ab") as f:
+            blob = "".join(json.dumps({"id": self.ids[n], "document": self.documents[n], "metadata": self.metadatas[n]}) + "\n" for n in range(first, len(self.ids))).encode("utf-8")
+            f.write(blob)
+            f.flush()
+            os.fsync(f.fileno())
         with open(os.path.join(d, "embeddings.f32"), "ab") as f:
             self._emb[first:].tofile(f)
-        with open(os.path.join(d, "meta.json"), "w") as f:
-            json.dump({"name": self.name, "metadata": self.metadata, "space": self.space, "dim": int(self._emb.shape[1]), "count": len(self.ids)}, f)
+            f.flush()
+            os.fsync(f.fileno())
+        self._rows_bytes += len(blob)
+        tmp = os.path.join(d, "meta.json.tmp")
+        with open(tmp, "w") as f:
+            json.dump({"name": self.name, "metadata": self.metadata, "space": self.space, "dim": int(self._emb.shape[1]), "count": len(self.ids), "rows_bytes": self._rows_bytes}, f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, os.path.join(d, "meta.json"))  # the commit
 
     # ---- the five methods the helper uses ------------------------------------------------------
     def count(self):
@@ -180,44 +288,142 @@ class Collection:
             raise ValueError("documents, metadatas and ids must have the same length")
         if len(set(ids)) != n:
             raise ValueError("duplicate ids in one add() call")
-        fresh = [j for j in range(n) if ids[j] not in self._index]  # existing ids are kept, not overwritten
-        if not fresh:
-            return
-        if embeddings is None:
-            if self._ef is None:
-                raise ValueError("no embeddings and no embedding function")
-            emb = self._ef.embed_tensor([documents[j] for j in fresh]).cpu().numpy() if hasattr(self._ef, "embed_tensor") else np.asarray(self._ef([documents[j] for j in fresh]), np.float32)
-        else:
-            emb = np.asarray(embeddings, np.float32)[fresh]
-        if self._emb.shape[0] == 0:
-            self._emb = np.zeros((0, emb.shape[1]), np.float32)
-        if emb.shape[1] != self._emb.shape[1]:
-            raise ValueError(f"embedding dimension {emb.shape[1]} != collection dimension {self._emb.shape[1]}")
-        first = len(self.ids)
-        for j in fresh:
-            self._index[ids[j]] = len(self.ids)
-            self.ids.append(ids[j])
-            self.documents.append(documents[j])
-            self.metadatas.append(metadatas[j])
-        # rows live in a buffer that doubles, so a long run of small adds stays linear
-        need = first + emb.shape[0]
-        buf = getattr(self, "_buf", None)
-        if buf is None or buf.shape[1] != emb.shape[1] or buf.shape[0] < need or buf[:first].base is not self._emb.base and not np.shares_memory(buf, self._emb):
-            cap = max(need, 2 * first, 1024)
-            nb = np.empty((cap, emb.shape[1]), np.float32)
-            nb[:first] = self._emb
-            self._buf = buf = nb
-        buf[first:need] = emb
-        self._emb = buf[:need]
-        self._corpus = None
-        self._append_to_disk(first)
+        d = self._dir()
+        if d:
+            os.makedirs(d, exist_ok=True)
+        with self._locked():
+            self._sync_from_disk()  # rows another process committed meanwhile: their ids count as existing
+            fresh = [j for j in range(n) if ids[j] not in self._index]  # existing ids are kept, not overwritten
+            if not fresh:
+                return
+            if embeddings is None:
+                if self._ef is None:
+                    raise ValueError("no embeddings and no embedding function")
+                docs = [documents[j] for j in fresh]
+                emb = self._ef.embed_tensor(docs).cpu().numpy() if hasattr(self._ef, "embed_tensor") else np.asarray(self._ef(docs), np.float32)
+            else:
+                emb = np.asarray(embeddings, np.float32)[fresh]
+            if self.ids and emb.shape[1] != self._emb.shape[1]:
+                raise ValueError(f"embedding dimension {emb.shape[1]} != collection dimension {self._emb.shape[1]}")
+            first = len(self.ids)
+            self._take_rows([ids[j] for j in fresh], [documents[j] for j in fresh], [metadatas[j] for j in fresh], emb)
+            self._append_to_disk(first)
 
     def _resident(self):
+        """The corpus handle over all rows: uploads and quantises only the rows added since the last call."""
+        eng = engine()
+        n, dim = self._emb.shape
+        if self._corpus is not None and self._dev_rows == n:
+            return self._corpus
+        if self._dev is None or self._dev.shape[0] < n or self._dev.shape[1] != dim:
+            nd = torch.empty((max(n, 2 * (self._dev.shape[0] if self._dev is not None else 0), 1024), dim), dtype=torch.float32, device=eng.device)
+            if self._dev is not None and self._dev_rows:
+                nd[: self._dev_rows] = self._dev[: self._dev_rows]
+            self._dev = nd
+        self._dev[self._dev_rows : n] = torch.from_numpy(self._emb[self._dev_rows : n]).to(eng.device)
         if self._corpus is None:
-            eng = engine()
-            self._dev = torch.from_numpy(self._emb).to(eng.device).contiguous()
-            self._corpus = eng.corpus(self._dev)
+            self._corpus = eng.corpus(self._dev, n=n)
+        else:
+            self._corpus.append(self._dev, n)
+        self._dev_rows = n
         return self._corpus
+
+    # ---- `where` -------------------------------------------------------------------------------
+    @staticmethod
+    def _code_of(st, value):
+        try:
+            return st["map"].setdefault(value, len(st["map"]))
+        except TypeError:  # an unhashable value (a list): never equal to a scalar operand
+            return -1
+
+    def _key_codes(self, key):
+        """int32 device tensor [count]: the code of every row's value under `key` (grown, not rebuilt, by adds)."""
+        eng = engine()
+        st = self._codes.get(key)
+        if st is None:
+            st = self._codes[key] = {"map": {}, "host": [], "dev": None, "n": 0}
+            st["host"] = [self._code_of(st, (m or {}).get(key)) for m in self.metadatas]
+        n = len(self.ids)
+        if st["n"] < n:
+            if st["dev"] is None or st["dev"].numel() < n:
+                nd = torch.empty(max(n, 2 * (st["dev"].numel() if st["dev"] is not None else 0), 1024), dtype=torch.int32, device=eng.device)
+                if st["n"]:
+                    nd[: st["n"]] = st["dev"][: st["n"]]
+                st["dev"] = nd
+            st["dev"][st["n"] : n] = torch.tensor(st["host"][st["n"] : n], dtype=torch.int32).to(eng.device)
+            st["n"] = n
+        return st
+
+    @staticmethod
+    def _device_filter(where):
+        """True when `where` uses only the forms the device evaluates: equality, $eq/$ne/$in/$nin, $and/$or."""
+        for key, cond in where.items():
+            if key in ("$and", "$or"):
+                if not all(isinstance(w, dict) and Collection._device_filter(w) for w in cond):
+                    return False
+            elif isinstance(cond, dict):
+                if not all(op in _DEVICE_OPS for op in cond):
+                    return False
+            elif isinstance(cond, (list, dict)):
+                return False
+        return True
+
+    def _where_mask(self, where):
+        """uint8 [count] on the device.  Equality forms (what the reference's callers build,
+        scripts/chromadb_helper.py:265-266) are evaluated there from cached per-key value codes; the rest
+        ($gt.., $contains) by `_match` over the host metadata."""
+        eng = engine()
+        n = len(self.ids)
+        if not self._device_filter(where):
+            keep = np.fromiter((_match(m, where) for m in self.metadatas), np.uint8, n)
+            return torch.from_numpy(keep).to(eng.device)
+        mask = torch.empty(n, dtype=torch.uint8, device=eng.device)
+        self._eval_where(where, mask, "set")
+        return mask
+
+    def _eval_where(self, where, mask, combine):
+        """mask <- combine(mask, AND of the clauses of `where`)."""
+        eng = engine()
+        n = mask.numel()
+        clauses = []  # (kind, payload): leaves first-class, groups through a temporary
+        for key, cond in where.items():
+            if key in ("$and", "$or"):
+                clauses.append(("group", (key, cond)))
+            elif isinstance(cond, dict):
+                for op, arg in cond.items():
+                    clauses.append(("leaf", (key, op, arg)))
+            else:
+                clauses.append(("leaf", (key, "$eq", cond)))
+        target = mask
+        if combine != "set" and len(clauses) != 1:
+            target = torch.empty(n, dtype=torch.uint8, device=eng.device)  # the clauses AND into a temporary first
+        if not clauses:
+            target.fill_(1)
+        for i, (kind, payload) in enumerate(clauses):
+            comb = ("set" if target is not mask or combine == "set" else combine) if i == 0 else "and"
+            if kind == "leaf":
+                key, op, arg = payload
+                st = self._key_codes(key)
+                args = list(arg) if op in ("$in", "$nin") else [arg]
+                vals = []
+                for a in args:
+                    try:
+                        if a in st["map"]:
+                            vals.append(st["map"][a])
+                    except TypeError:
+                        pass
+                values = torch.tensor(vals, dtype=torch.int32).to(eng.device) if vals else None
+                eng.row_mask_update(target, codes=st["dev"], values=values, negate=op in ("$ne", "$nin"), combine=comb)
+            else:
+                key, subs = payload
+                tmp = torch.empty(n, dtype=torch.uint8, device=eng.device)
+                if not subs:
+                    tmp.fill_(1 if key == "$and" else 0)
+                for j, w in enumerate(subs):
+                    self._eval_where(w, tmp, "set" if j == 0 else ("and" if key == "$and" else "or"))
+                eng.row_mask_update(target, other=tmp, combine=comb)
+        if target is not mask:
+            eng.row_mask_update(mask, other=target, combine=combine)
 
     def query(self, query_texts=None, n_results=10, include=None, where=None, query_embeddings=None):
         include = list(include) if include is not None else ["documents", "metadatas", "distances"]
@@ -232,12 +438,10 @@ class Collection:
         rows = dist = None
         if self.count() and n_results > 0:
             k = min(int(n_results), self.count())
-            mask = None
-            if where:
-                keep = np.fromiter((_match(m, where) for m in self.metadatas), np.uint8, len(self.metadatas))
-                mask = torch.from_numpy(keep).to(eng.device)
+            corpus = self._resident()
+            mask = self._where_mask(where) if where else None
             if k <= MAX_K:
-                d, r = eng.score_topk(self._resident(), q.contiguous(), k, space=self.space, mask=mask)
+                d, r = eng.score_topk(corpus, q.contiguous(), k, space=self.space, mask=mask)
             else:
                 d, r = self._topk_beyond_max(q.contiguous(), k, mask)
             rows, dist = r.cpu().numpy(), d.cpu().numpy()
@@ -254,27 +458,21 @@ class Collection:
         return res
 
     def _topk_beyond_max(self, q, k, mask):
-        """More results than one scan returns (n_results is unbounded in the reference): per query, passes of
-        MAX_K with the rows already returned masked out.  The order is total (distance, then row), so the
-        passes concatenate to the exact top-k."""
+        """More results than one scan returns (n_results is unbounded in the reference): passes of MAX_K for the
+        whole batch, each resumed behind the last key every query has received (hrs_score_topk_after).  The order
+        is total (distance, then row), so the passes concatenate to the exact top-k."""
         eng = engine()
-        n = self.count()
-        dist = torch.full((q.shape[0], k), float("inf"), dtype=torch.float32, device=eng.device)
-        rows = torch.full((q.shape[0], k), -1, dtype=torch.int64, device=eng.device)
-        for b in range(q.shape[0]):
-            keep = mask.clone() if mask is not None else torch.ones(n, dtype=torch.uint8, device=eng.device)
-            got = 0
-            while got < k:
-                step = min(MAX_K, k - got)
-                d, r = eng.score_topk(self._resident(), q[b : b + 1], step, space=self.space, mask=keep)
-                found = int((r[0] >= 0).sum())
-                dist[b, got : got + found] = d[0, :found]
-                rows[b, got : got + found] = r[0, :found]
-                got += found
-                if found < step:
-                    break
-                keep[r[0, :found]] = 0
-        return dist, rows
+        corpus = self._resident()
+        d, r, keys = eng.score_topk(corpus, q, MAX_K, space=self.space, mask=mask, want_keys=True)
+        dist, rows = [d], [r]
+        got = MAX_K
+        while got < k:
+            step = min(MAX_K, k - got)
+            d, r, keys = eng.score_topk_after(corpus, q, step, keys[:, -1].contiguous(), space=self.space, mask=mask)
+            dist.append(d)
+            rows.append(r)
+            got += step
+        return torch.cat(dist, dim=1), torch.cat(rows, dim=1)
 
     def peek(self, limit=10):
         n = min(limit, self.count())
@@ -293,6 +491,7 @@ class Client:
         self._open = {}
 
     def get_or_create_collection(self, name, embedding_function=None, metadata=None):
+        validate_name(name)
         if name not in self._open:
             self._open[name] = Collection(self, name, embedding_function, metadata)
         col = self._open[name]
@@ -303,5 +502,5 @@ class Client:
     def list_collections(self):
         names = set(self._open)
         if self.path and os.path.isdir(self.path):
-            names |= {d for d in os.listdir(self.path) if os.path.exists(os.path.join(self.path, d, "meta.json"))}
+            names |= {d for d in os.listdir(self.path) if _NAME_RE.match(d) and os.path.exists(os.path.join(self.path, d, "meta.json"))}
         return [self.get_or_create_collection(n) for n in sorted(names)]

@@ -106,6 +106,13 @@ int hrs_tokenize(hrs_tokenizer* tok, const char* texts, const int64_t* offs, int
 int hrs_corpus_register(hrs_ctx* ctx, const float* C_dev, int64_t N, int D, int64_t row_offset, void* stream,
                         hrs_corpus** out);
 int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* corpus);
+/* A further collection.add(...) on the same collection (scripts/chromadb_helper.py:397-401, 462-466, 474-478):
+ * the matrix now holds N >= the registered rows; the rows registered before are unchanged but may have moved
+ * (C_dev replaces the pointer the handle keeps).  Only the new rows, and the last partly filled 32-row group,
+ * are quantised into the shadow, whose allocation doubles when full -- the cost of an append does not depend
+ * on the size of the collection (a doubling copies the shadow and waits for `stream`).  Work is enqueued on
+ * `stream`; calls that read the corpus must be ordered behind it. */
+int hrs_corpus_append(hrs_ctx* ctx, hrs_corpus* corpus, const float* C_dev, int64_t N, void* stream);
 /* Rebuilds the corpus' shadow as `kind` (hrs_shadow_kind) on `stream`; waits for the device first.
  * No counterpart in the reference (ChromaDB's index parameters are fixed at collection creation,
  * scripts/chromadb_helper.py:82-86); NONE leaves only the exact scan. */
@@ -125,6 +132,14 @@ int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* corpus, void* stream, double* min
 int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
                    const uint8_t* row_mask_dev, int mode, uint64_t* keys_dev, float* dist_dev, int64_t* rows_dev,
                    void* stream);
+
+/* hrs_score_topk resumed behind earlier results, for n_results beyond HRS_MAX_K (collection.query does not bound
+ * n_results, scripts/chromadb_helper.py:259-269): only rows whose key is strictly greater than after_keys_dev[b]
+ * (uint64 [B]: the last key query b has received; HRS_PAD_KEY = nothing left) are eligible.  The order is total,
+ * so consecutive calls concatenate to the exact top-n.  Exact streaming scan; other arguments as hrs_score_topk. */
+int hrs_score_topk_after(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
+                         const uint8_t* row_mask_dev, const uint64_t* after_keys_dev, uint64_t* keys_dev, float* dist_dev,
+                         int64_t* rows_dev, void* stream);
 
 /* hrs_score_topk in two halves, for callers that pipeline batches over two contexts joined by
  * hrs_ctx_set_peer (no counterpart in the reference, which serves one query per process,
@@ -187,6 +202,15 @@ int hrs_encoder_release(hrs_ctx* ctx, hrs_encoder* enc);
  * 32 in [32, 256]; out_dev fp32 [B, hidden] unit-norm sentence embeddings. */
 int hrs_encode(hrs_ctx* ctx, hrs_encoder* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int S,
                float* out_dev, void* stream);
+
+/* ---- the `where` filter -------------------------------------------------------------------- */
+/* Builds the row mask that hrs_score_topk takes from per-key value codes kept on the device, for the equality
+ * forms of ChromaDB's `where` (scripts/chromadb_helper.py:265-266: {"system": S}; also $eq/$ne/$in/$nin/$and/$or).
+ * t_i = codes_dev ? ((codes_dev[i] is one of values_dev[0..m)) != negate) : (other_dev[i] != 0)  -- exactly one of
+ * codes_dev (int32 [N], the host's code of row i's value under one metadata key) and other_dev (uint8 [N],
+ * another mask) is given; mask_dev[i] = t_i (combine 0), mask_dev[i] AND t_i (1), mask_dev[i] OR t_i (2). */
+int hrs_row_mask_update(hrs_ctx* ctx, int64_t N, const int32_t* codes_dev, const int32_t* values_dev, int m, int negate,
+                        const uint8_t* other_dev, int combine, uint8_t* mask_dev, void* stream);
 
 /* ---- keyword side -------------------------------------------------------------------------- */
 /* Forward CSR postings of this shard: the term ids of row i are

@@ -159,3 +159,54 @@ def test_more_results_than_one_scan_returns(tmp_path):
             assert len(want) == min(kk, int(keep.sum()))
             assert res["ids"][b] == [f"id{r}" for r in want], (k, where, b)
             assert res["distances"][b] == [float(x) for x in wd[b][: len(want)]]
+
+
+def test_incremental_collection_and_device_side_where(tmp_path):
+    """Rows arrive in many small adds between queries: the device matrix, its shadow and the per-key metadata
+    codes behind `where` are extended, never rebuilt, and every query equals the oracle over the rows kept by the
+    host-side `_match` -- for the equality forms the device evaluates ($eq/$ne/$in/$nin/$and/$or, nested, missing
+    keys, None, unknown values) and for the forms that stay on the host."""
+    from hybrid_rag_system_amd.store import Client, _match
+
+    rng = np.random.default_rng(9)
+    d, total = 32, 2600
+    emb = rng.standard_normal((total, d)).astype(np.float32)
+    systems = ["docker", "unraid", "proxmox", None]
+    metas = []
+    for i in range(total):
+        m = {"system": systems[i % 4], "n": i % 7, "flag": bool(i % 2)}
+        if i % 5 == 0:
+            del m["system"]  # a missing key
+        if i % 11 == 0:
+            m = None
+        metas.append(m)
+    col = Client(str(tmp_path)).get_or_create_collection("inc-where")
+    q = rng.standard_normal((3, d)).astype(np.float32)
+    wheres = [
+        {"system": "docker"},
+        {"system": {"$ne": "docker"}},
+        {"system": {"$in": ["unraid", "proxmox", "nothing"]}},
+        {"system": {"$nin": ["unraid"]}, "n": {"$in": [1, 2, 3]}},
+        {"$or": [{"system": "unraid"}, {"$and": [{"n": 3}, {"flag": True}]}]},
+        {"$and": [{"$or": [{"n": 0}, {"n": 1}]}, {"system": {"$ne": "proxmox"}}], "flag": False},
+        {"system": "no-such-system"},
+        {"system": None},
+        {"$or": []},
+        {"n": {"$gte": 2, "$lt": 5}},  # evaluated on the host
+    ]
+    have = 0
+    for step in (1100, 7, 1, 40, 1300, 152):
+        ids = [f"id{i}" for i in range(have, have + step)]
+        col.add(documents=[f"doc {i}" for i in ids], metadatas=metas[have : have + step], ids=ids, embeddings=emb[have : have + step])
+        have += step
+        for where in wheres:
+            keep = np.array([_match(m, where) for m in col.metadatas], np.uint8)
+            res = col.query(query_embeddings=q, n_results=9, where=where)
+            wd, wr = so.topk(q, emb[:have], 9, "l2", mask=keep)
+            for b in range(3):
+                want = [int(r) for r in wr[b] if r >= 0]
+                assert res["ids"][b] == [f"id{r}" for r in want], (have, where, b)
+                assert res["distances"][b] == [float(x) for x in wd[b][: len(want)]]
+    assert col._corpus.n == total and col._dev.shape[0] >= total
+    again = Client(str(tmp_path)).get_or_create_collection("inc-where")
+    assert again.count() == total and again.query(query_embeddings=q, n_results=4)["ids"] == col.query(query_embeddings=q, n_results=4)["ids"]

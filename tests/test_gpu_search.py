@@ -473,3 +473,90 @@ def test_synth_rows_shard_invariant(eng):
     pn = p.cpu().numpy()
     assert (np.diff(pn, axis=1) > 0).all() and pn.min() >= 0 and pn.max() < 5000
     assert (pn == 0).any(axis=1).mean() > 0.5  # the most popular term is in most rows (Zipf)
+
+
+@pytest.mark.parametrize("shadow,d", [("i8", 384), ("bf16", 384), ("bf16", 1024), ("none", 384)])
+def test_corpus_append_equals_fresh_registration(eng, shadow, d):
+    """hrs_corpus_append: rows arrive in ragged batches (partly filled 32-row groups are re-quantised, the shadow's
+    allocation doubles twice); after every append the matrix-core path and the exact scan return the keys of a
+    corpus registered in one go -- the oracle's."""
+    rng = np.random.default_rng(17 + d)
+    sizes = [70_001, 13, 19, 1, 40_000, 95_000, 31]
+    total = sum(sizes)
+    C = _unit(rng, total, d)
+    C[total - 5] = C[3]
+    Q = _unit(rng, 48, d)
+    Q[0] = C[3]
+    buf = torch.empty((total, d), dtype=torch.float32, device="cuda")
+    n = sizes[0]
+    buf[:n] = torch.from_numpy(C[:n]).cuda()
+    corpus = eng.corpus(buf, shadow=shadow, n=n)
+    dq = torch.from_numpy(Q).cuda()
+    for step in sizes[1:]:
+        buf[n : n + step] = torch.from_numpy(C[n : n + step]).cuda()
+        n += step
+        corpus.append(buf, n)
+        if step in (1, 95_000, 31):
+            want = so.topk_keys(Q, C[:n], 10, "l2")
+            for mode in ("mfma", "exact"):
+                _, _, keys = eng.score_topk(corpus, dq, 10, mode=mode, want_keys=True)
+                torch.cuda.synchronize()
+                assert np.array_equal(_keys(keys), want), (n, mode, eng.score_stats())
+    mn, mx = corpus.norm_stats()
+    nn = (C.astype(np.float64) ** 2).sum(1)
+    assert abs(mn - nn.min()) < 1e-9 and abs(mx - nn.max()) < 1e-9
+    # moved to a new address (the caller's buffer was reallocated) and grown from empty
+    moved = torch.from_numpy(C).cuda()
+    corpus.append(moved, total)
+    _, _, keys = eng.score_topk(corpus, dq, 10, mode="mfma", want_keys=True)
+    assert np.array_equal(_keys(keys), so.topk_keys(Q, C, 10, "l2"))
+    corpus.close()
+    empty = eng.corpus(moved, n=0)
+    empty.append(moved, 5000)
+    _, _, keys = eng.score_topk(empty, dq, 10, want_keys=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_keys(keys), so.topk_keys(Q, C[:5000], 10, "l2"))
+    empty.close()
+
+
+def test_norm_stats_without_a_shadow(eng):
+    rng = np.random.default_rng(3)
+    C = (rng.standard_normal((3000, 1500)) * rng.uniform(0.1, 3, (3000, 1))).astype(np.float32)  # deeper than any shadow
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    mn, mx = corpus.norm_stats()
+    nn = (C.astype(np.float64) ** 2).sum(1)
+    assert abs(mn / nn.min() - 1) < 1e-12 and abs(mx / nn.max() - 1) < 1e-12
+    corpus.close()
+
+
+def test_topk_resumed_behind_a_key_concatenates_to_the_exact_order(eng):
+    """hrs_score_topk_after: three passes of 128 resumed behind each query's last key equal one top-384 of the oracle,
+    including through a run of exact ties that straddles a pass boundary and a query that runs out of rows."""
+    rng = np.random.default_rng(23)
+    n, d, b = 5000, 64, 6
+    C = _unit(rng, n, d)
+    C[100:400] = C[7]  # 301 exact ties: the boundary of pass 1 falls inside the run
+    Q = _unit(rng, b, d)
+    Q[0] = C[7]
+    mask = np.ones(n, np.uint8)
+    mask[rng.random(n) < 0.5] = 0
+    want = so.topk_keys(Q, C, 384, "l2")
+    wantm = so.topk_keys(Q, C, 384, "l2", mask=mask)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    dq = torch.from_numpy(Q).cuda()
+    for m, w in ((None, want), (torch.from_numpy(mask).cuda(), wantm)):
+        _, _, keys = eng.score_topk(corpus, dq, 128, mask=m, want_keys=True)
+        got = [keys]
+        for _ in range(2):
+            _, _, keys = eng.score_topk_after(corpus, dq, 128, got[-1][:, -1].contiguous(), mask=m)
+            got.append(keys)
+        torch.cuda.synchronize()
+        assert np.array_equal(_keys(torch.cat(got, dim=1)), w)
+    small = eng.corpus(torch.from_numpy(C[:150]).cuda())
+    _, r1, k1 = eng.score_topk(small, dq, 128, want_keys=True)
+    _, r2, k2 = eng.score_topk_after(small, dq, 128, k1[:, -1].contiguous())
+    _, r3, _ = eng.score_topk_after(small, dq, 128, k2[:, -1].contiguous())
+    torch.cuda.synchronize()
+    assert (r2[:, :22] >= 0).all() and (r2[:, 22:] == -1).all() and (r3 == -1).all()
+    small.close()
+    corpus.close()

@@ -122,6 +122,21 @@ def test_protocol_edges(served):
     col = a.get_or_create_collection("d", metadata={"k": 1})
     col.add(documents=[big], metadatas=[{"n": 1}], ids=["id0"])
     assert col.count() == 1 and col.metadata == {"k": 1} and b.get_or_create_collection("d").peek(1)["documents"][0] == big
+    # a request that is not a JSON object is answered with an error and the server lives on
+    import json as _json
+    import socket as _socket
+    import struct as _struct
+
+    raw = _socket.socket(_socket.AF_UNIX, _socket.SOCK_STREAM)
+    raw.connect(addr)
+    body = _json.dumps([]).encode()
+    raw.sendall(_struct.pack(">I", len(body)) + body)
+    (n,) = _struct.unpack(">I", raw.recv(4))
+    ans = _json.loads(raw.recv(n))
+    assert ans["ok"] is False and "JSON object" in ans["error"]
+    raw.close()
+    assert a.call("ping")["pid"] == os.getpid()
+    assert oct(os.stat(addr).st_mode & 0o777) == "0o600"
     a.close(), b.close()
     with pytest.raises(ConnectionError, match="no engine server"):
         remote.RemoteClient(addr + ".absent")
