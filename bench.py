@@ -8,19 +8,22 @@ counts of those 20 rows over forward-CSR postings, fused score 0.7*sem + 0.3*kw,
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 there are two layouts.  `replica` (what `auto` picks when the whole corpus with its shadow
-and postings fits one GPU's HBM several times over, as 10M x 384 does: 23 GB of 288 GB): every rank
-holds the corpus and answers its own batch of 1024 queries -- queries are independent units, no
-data-path collective, weak scaling (per-GPU work fixed).  `shard` (corpora beyond one GPU, BASELINE
-config 5; forced with --layout shard): the rows are sharded over the ranks, every rank scores the same
-batch against its shard and every batch ends with one all-gather of the per-shard candidates (RCCL)
-and a merge -- strong scaling (total work fixed).  Rank 0 prints ONE JSON line.
+With N > 1 the headline is the row-shard layout: the corpus rows (and their term lists) are split over the
+ranks, every rank scores the same batch against its shard, and every batch ends with ONE all-gather of the
+per-shard candidates (RCCL over xGMI: B x 2n x 16 bytes per rank) and a merge on every rank -- strong scaling
+(total work fixed).  The replica layout (every rank holds the whole corpus and answers its own batch; no
+data-path collective, weak scaling) is measured after it and reported under "extras" when the corpus fits
+one GPU (--layout replica makes it the headline instead).  Rank 0 prints ONE JSON line.
+
+The 100M x 1024 configuration (BASELINE.json config 5; 12.5M rows = 51 GB fp32 per GPU, top-100 candidates):
+  python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --rows 100000000 --dim 1024 --n-results 50 --space cosine
 """
 import argparse
 import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 import torch
@@ -35,6 +38,10 @@ SEED_CORPUS, SEED_QUERY, SEED_TERMS, SEED_POST = 1235, 4321, 777, 99
 VOCAB, TERMS_PER_DOC = 50_000, 96
 MFMA_PEAK_TFLOPS = {"i8": 5000.0, "bf16": 2500.0}  # dense matrix-core peaks of MI355X (int8 counts integer ops)
 HBM_PEAK_GBPS = 8000.0
+# what this chip has been measured to sustain (for the "of measured" fractions beside the spec ones): a plain copy
+# kernel (the MI355X guide's figure) and an LDS-fed MFMA loop on random operands (profiles/r01_mfma_micro.txt)
+HBM_MEASURED_GBPS = 6290.0
+MFMA_MEASURED_TFLOPS = {"i8": 2750.0, "bf16": 1250.0}
 
 
 def zipf_cdf(V, device):
@@ -106,7 +113,7 @@ def cpu_baseline(corpus_matrix, terms, queries, q_terms, q_offs, n_keep, n_total
     }
 
 
-def bench_embed(eng, batches=4, B=1024, S=256, cpu_chunks=32):
+def bench_embed(eng, batches=4, B=1024, S=256, cpu_chunks=2048):
     """BASELINE config 3 shape: MiniLM-L6 embedding of full-length (256-token) synthetic chunks, batch 1024;
     beside it the fp32 oracle (torch on the host cores, sentence-transformers' default batch of 32)."""
     from hybrid_rag_system_amd import weights as W
@@ -157,13 +164,22 @@ def bench_embed(eng, batches=4, B=1024, S=256, cpu_chunks=32):
     if cpu_chunks:
         from oracle import encoder_oracle as EO  # the checker, timed as the CPU baseline of this extra
 
-        hid, hl = ids[:cpu_chunks].cpu().numpy(), lens[:cpu_chunks].cpu().numpy()
+        # sentence-transformers' default on the reference's CPU path: batches of 32
+        reps = (cpu_chunks + B - 1) // B
+        hid = ids.cpu().numpy()
+        hl = lens.cpu().numpy()
         EO.forward(wts, hid[:4], hl[:4], cfg)
         t0 = time.perf_counter()
-        EO.forward(wts, hid, hl, cfg)
+        done = 0
+        for r in range(reps):
+            for s0 in range(0, B, 32):
+                if done >= cpu_chunks:
+                    break
+                EO.forward(wts, hid[s0 : s0 + 32], hl[s0 : s0 + 32], cfg)
+                done += 32
         cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": cpu_chunks / cdt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"oracle/encoder_oracle.py (fp32 torch) on {cpu_chunks} chunks x {S} tokens in {cdt:.2f}s"}
+        out["cpu_baseline"] = {"value": done / cdt, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/encoder_oracle.py (fp32 torch) on {done} chunks x {S} tokens in batches of 32 in {cdt:.2f}s"}
     return out
 
 
@@ -186,7 +202,9 @@ def bench_scan(eng, corpus, queries, k=10):
 
 
 def bench_other_configs(eng):
-    """BASELINE configs 2 and 5 on one GPU: plain exact top-k scoring (no keyword stage), MFMA path."""
+    """BASELINE configs 2 and 5 (one shard) on one GPU: plain exact top-k scoring (no keyword stage), MFMA path.
+    Checked figures: the exact fallback must stay the exception and a sample of the batch must equal the fp64
+    streaming scan's keys bit for bit, or the run aborts."""
     out = {}
     for name, n, D, B, k in (("config2_1Mx384_cosine_top10_batch256", 1_000_000, 384, 256, 10),
                              ("config5_one_shard_12.5Mx1024_cosine_top100_batch1024", 12_500_000, 1024, 1024, 100)):
@@ -196,9 +214,15 @@ def bench_other_configs(eng):
             eng.synth_rows(SEED_CORPUS + 5, r0, nr, D, out=m[r0 : r0 + nr])
         c = eng.corpus(m)
         q = eng.synth_rows(SEED_QUERY + 5, 0, B, D)
-        eng.score_topk(c, q, k, space="cosine", mode="mfma")
+        _, _, keys = eng.score_topk(c, q, k, space="cosine", mode="mfma", want_keys=True)
         torch.cuda.synchronize()
         st = eng.score_stats()
+        if st["fallback_queries"] > B // 100 or st["overflow_queries"]:
+            raise SystemExit(f"{name}: {st} -- the matrix-core path did not prove its results")
+        sel = torch.tensor([0, 1, B // 2, B - 1], device=eng.device)
+        _, _, kx = eng.score_topk(c, q[sel].contiguous(), k, space="cosine", mode="exact", want_keys=True)
+        if not torch.equal(keys[sel], kx):
+            raise SystemExit(f"{name}: matrix-core keys differ from the exact scan's")
         eng.profile(True)
         reps = 5
         t0 = time.perf_counter()
@@ -209,11 +233,104 @@ def bench_other_configs(eng):
         ms, nl = eng.profile_read()
         eng.profile(False)
         out[name] = {"ms_per_batch": dt * 1e3, "queries_per_s": B / dt, "scan_kernel_ms": ms / max(nl, 1),
-                     "scan_TFLOPs": 2.0 * n * D * B / (ms / max(nl, 1) * 1e-3) / 1e12, "fallback_queries": st["fallback_queries"]}
+                     "scan_TFLOPs": 2.0 * n * D * B / (ms / max(nl, 1) * 1e-3) / 1e12, "fallback_queries": st["fallback_queries"],
+                     "checked": "4 sampled queries equal the exact scan's keys"}
         c.close()
         del m, c
         torch.cuda.empty_cache()
     return out
+
+
+def bench_text_queries(eng, searcher, n_keep, B=1024, reps=5):
+    """End to end from TEXT: tokenise B short queries (host threads), encode them (MiniLM geometry, generated
+    weights), extract keywords (host), then the hybrid step over the resident corpus."""
+    from hybrid_rag_system_amd import textproc
+    from hybrid_rag_system_amd.store import HrsEmbeddingFunction
+    import hybrid_rag_system_amd.store as store
+
+    store._ENGINE = eng
+    ef = HrsEmbeddingFunction()
+    rng = np.random.default_rng(11)
+    words = ["restart", "docker", "container", "unraid", "backup", "schedule", "proxmox", "firewall", "address", "powershell", "filter",
+             "network", "storage", "array", "parity", "service", "status", "failed", "certificate", "renewal", "tunnel", "forwarding",
+             "how", "do", "the", "on", "with", "what", "is", "of"]
+    texts = [" ".join(rng.choice(words, int(rng.integers(5, 12)))) for _ in range(B)]
+
+    def once():
+        kws = [textproc.extract_keywords(t) for t in texts]
+        offs = np.zeros(B + 1, np.int32)
+        offs[1:] = np.cumsum([len(k) for k in kws])
+        terms = np.fromiter((zlib.crc32(w.encode()) % VOCAB for k in kws for w in k), np.int32, int(offs[-1]))
+        q = ef.embed_tensor(texts)
+        return searcher.step(q.contiguous(), torch.from_numpy(terms).to(eng.device), torch.from_numpy(offs).to(eng.device), n_keep)
+
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ef.encoder.close()
+    return {"queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "config": f"{B} text queries of 5-11 words: host tokeniser + keyword extraction, GPU encoder, hybrid top-{n_keep}"}
+
+
+def build_rank_state(eng, dev, n_total, D, lo, hi, shadow):
+    """This rank's rows [lo, hi) of the synthetic corpus, its shadow and its postings."""
+    n_local = hi - lo
+    matrix = torch.empty((n_local, D), dtype=torch.float32, device=dev)
+    step_rows = 1 << 20
+    for r0 in range(0, n_local, step_rows):
+        nr = min(step_rows, n_local - r0)
+        eng.synth_rows(SEED_CORPUS, lo + r0, nr, D, out=matrix[r0 : r0 + nr])
+    corpus = eng.corpus(matrix, row_offset=lo, shadow=shadow)
+    cdf = zipf_cdf(VOCAB, dev)
+    terms = eng.synth_postings(SEED_POST, lo, n_local, cdf, TERMS_PER_DOC)
+    doc_offs = torch.arange(n_local + 1, dtype=torch.int64, device=dev) * TERMS_PER_DOC
+    postings = eng.postings(doc_offs, terms.reshape(-1), row_offset=lo)
+    return matrix, corpus, terms, postings
+
+
+def timed_run(engines, corpus, postings, group, queries, q_terms, q_offs, n_keep, args, world, rehearsal, dev):
+    """W warmup + K timed steps through the two-stream pipeline -> (max-over-ranks seconds, kernel ms, launches, stats, pipeline)."""
+    import torch.distributed as dist
+
+    eng = engines[0]
+    searcher = HybridPipeline(engines, corpus, postings, group=group)
+
+    def step():
+        return searcher.submit(queries, q_terms, q_offs, n_keep, mode=args.mode, space=args.space)
+
+    for _ in range(len(engines)):  # every engine sizes its workspaces before the warmup proper
+        step()
+    searcher.drain()
+    for _ in range(args.warmup):
+        step()
+    searcher.drain()
+    torch.cuda.synchronize()
+    stats = eng.score_stats()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    eng.profile(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    searcher.drain()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, kern_ms, launches, stats, searcher
 
 
 def main():
@@ -225,14 +342,15 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--n-results", type=int, default=10)
+    ap.add_argument("--space", default="l2", choices=["l2", "cosine", "ip"], help="distance of the collection (the reference's default space is l2)")
     ap.add_argument("--mode", default="auto", choices=["auto", "exact", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=128)
+    ap.add_argument("--cpu-sample-queries", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3], help="consecutive batches alternate over this many HIP streams (1: strictly back to back)")
-    ap.add_argument("--layout", default="auto", choices=["auto", "replica", "shard"], help="multi-GPU layout (auto: replica when the corpus fits one GPU with room to spare)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "replica", "shard"], help="multi-GPU layout of the headline (auto: shard -- the rows split over the ranks, one all-gather per batch)")
     ap.add_argument("--shadow", default="auto", choices=["auto", "i8", "bf16"], help="scan shadow of the corpus (auto: int8 up to depth 512)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the embed / small-batch scan side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (embed, small-batch scan, other configs, text queries, replica layout)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -247,9 +365,10 @@ def main():
         import faulthandler
 
         local_rank = 0
-        faulthandler.dump_traceback_later(120, exit=True)  # a rehearsal that stops says where
+        faulthandler.dump_traceback_later(300, exit=True)  # a rehearsal that stops says where
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
@@ -257,26 +376,18 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend()
     eng = Engine(local_rank)
 
     n_total, D, B, n_keep = args.rows, args.dim, args.batch, args.n_results
     footprint = n_total * (D * 4 + D * 2 + TERMS_PER_DOC * 4 + 8)  # fp32 rows + largest shadow + postings
-    layout = args.layout if args.layout != "auto" else ("replica" if footprint <= 96e9 else "shard")
-    if world == 1:
-        layout = "single"
+    layout = "single" if world == 1 else ("shard" if args.layout == "auto" else args.layout)
+    if layout == "replica" and footprint > 200e9:
+        raise SystemExit("--layout replica: the corpus does not fit one GPU")
     lo, hi = shard_bounds(n_total, world, rank) if layout == "shard" else (0, n_total)
     n_local = hi - lo
-    matrix = torch.empty((n_local, D), dtype=torch.float32, device=dev)
-    step_rows = 1 << 20
-    for r0 in range(0, n_local, step_rows):
-        nr = min(step_rows, n_local - r0)
-        eng.synth_rows(SEED_CORPUS, lo + r0, nr, D, out=matrix[r0 : r0 + nr])
-    corpus = eng.corpus(matrix, row_offset=lo, shadow=args.shadow)
+    matrix, corpus, terms, postings = build_rank_state(eng, dev, n_total, D, lo, hi, args.shadow)
     shadow = args.shadow if args.shadow != "auto" else ("i8" if D <= 512 else "bf16")
-    cdf = zipf_cdf(VOCAB, dev)
-    terms = eng.synth_postings(SEED_POST, lo, n_local, cdf, TERMS_PER_DOC)
-    doc_offs = torch.arange(n_local + 1, dtype=torch.int64, device=dev) * TERMS_PER_DOC
-    postings = eng.postings(doc_offs, terms.reshape(-1), row_offset=lo)
     queries = make_queries(eng, B, D, n_total, stream=rank if layout == "replica" else 0)
     q_terms, q_offs = make_query_terms(B, dev)
     torch.cuda.synchronize()
@@ -284,41 +395,22 @@ def main():
     # batch i runs on stream i % streams (one engine = one set of workspaces per stream); the dominant
     # kernel is timed on the first engine's launches
     engines = [eng] + [Engine(local_rank) for _ in range(max(args.streams, 1) - 1)]
-    searcher = HybridPipeline(engines, corpus, postings, group=False if layout != "shard" else None)
+    elapsed, kern_ms, launches, stats, searcher = timed_run(engines, corpus, postings, None if layout == "shard" else False, queries, q_terms,
+                                                            q_offs, n_keep, args, world, rehearsal, dev)
+    bytes_gathered = searcher.lanes[0][0].bytes_gathered
 
-    def step():
-        return searcher.submit(queries, q_terms, q_offs, n_keep, mode=args.mode)
-
-    for _ in range(len(engines)):  # every engine sizes its workspaces before the warmup proper
-        out = step()
-    searcher.drain()
-
-    for _ in range(args.warmup):
-        out = step()
-    searcher.drain()
-    torch.cuda.synchronize()
-    stats = eng.score_stats()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    eng.profile(True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    searcher.drain()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms, launches = eng.profile_read()
-    eng.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the replica layout beside a sharded headline (when the whole corpus fits one GPU next to the shard)
+    replica = None
+    if layout == "shard" and not args.no_extras and footprint <= 96e9:
+        corpus.close()
+        postings.close()
+        del matrix, corpus, terms, postings, searcher
+        torch.cuda.empty_cache()
+        matrix, corpus, terms, postings = build_rank_state(eng, dev, n_total, D, 0, n_total, args.shadow)
+        rq = make_queries(eng, B, D, n_total, stream=rank)
+        r_elapsed, _, _, _, _ = timed_run(engines, corpus, postings, False, rq, q_terms, q_offs, n_keep, args, world, rehearsal, dev)
+        replica = {"queries_per_s": B * args.steps * world / r_elapsed, "ms_per_step": r_elapsed / args.steps * 1e3, "scaling": "weak",
+                   "parallelism": f"query-parallel x{world}: corpus replicated, {B} queries per GPU per step, no data-path collective"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -330,21 +422,29 @@ def main():
             flops = 2.0 * B * n_local * D  # algorithmic: 2*B*N*D per pass of this GPU's shard
             achieved = flops / (kern_avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[shadow]
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "kernel": f"k_mfma_scan<main,{shadow}>", "kernel_ms": kern_avg_ms}
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "kernel": f"k_mfma_scan<main,{shadow}>", "kernel_ms": kern_avg_ms,
+                    "peak_measured": MFMA_MEASURED_TFLOPS[shadow], "frac_of_measured": achieved / MFMA_MEASURED_TFLOPS[shadow],
+                    "peak_measured_source": "LDS-fed MFMA loop on random operands, profiles/r01_mfma_micro.txt"}
         else:
             passes = (B + 3) // 4
             nbytes = float(n_local) * D * 4 * passes  # fp32 corpus streamed once per pass of 4 queries
             achieved = nbytes / (kern_avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_exact_scan", "kernel_ms": kern_avg_ms}
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_exact_scan", "kernel_ms": kern_avg_ms,
+                    "peak_measured": HBM_MEASURED_GBPS, "frac_of_measured": achieved / HBM_MEASURED_GBPS, "peak_measured_source": "copy kernel, MI355X guide"}
+        # HBM bytes per launch cannot be counted from inside the run (PMC counters need rocprofv3): what a
+        # separate --pmc pass over this same command recorded, with its source, for this exact shape only
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file) and (n_local, D, B) == (10_000_000, 384, 1024):  # measured for this shape only
+        if os.path.exists(traffic_file) and (n_local, D, B) == (10_000_000, 384, 1024):
             try:
                 with open(traffic_file) as f:
-                    roof["traffic"] = json.load(f).get(roof["kernel"])
+                    tj = json.load(f)
+                if roof["kernel"] in tj:
+                    roof["traffic_recorded"] = {"bytes_per_launch": tj[roof["kernel"]], "source": tj.get("source", "profiles/traffic.json"), "how": tj.get("note")}
             except Exception:
                 pass
+        par = {"single": "single GPU", "shard": f"row-shard x{world}, one all-gather per batch", "replica": f"query-parallel x{world}: corpus replicated, {B} queries per GPU per step, no data-path collective"}[layout]
         line = {
-            "metric": "hybrid top-10 queries/sec over 10M x 384 corpus",
+            "metric": f"hybrid top-{n_keep} queries/sec over {n_total // 1_000_000}M x {D} corpus" if (n_total, D, n_keep) != (10_000_000, 384, 10) else "hybrid top-10 queries/sec over 10M x 384 corpus",
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
@@ -357,13 +457,14 @@ def main():
             "dtype": f"{shadow} MFMA scan + fp64 exact re-score" if used_mfma else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"hybrid squared-L2 top-{2 * n_keep} + keyword counts + fusion -> top-{n_keep}; {n_total} x {D} fp32 corpus (unit rows), {VOCAB}-term Zipf postings ({TERMS_PER_DOC}/doc), batch {B}",
+                "workload": f"hybrid {args.space} top-{2 * n_keep} + keyword counts + fusion -> top-{n_keep}; {n_total} x {D} fp32 corpus (unit rows), {VOCAB}-term Zipf postings ({TERMS_PER_DOC}/doc), batch {B}",
                 "rows_total": n_total,
                 "rows_per_gpu": n_local,
                 "dim": D,
                 "batch": B,
                 "n_results": n_keep,
-                "parallelism": {"single": "single GPU", "shard": f"row-shard x{world}, one all-gather per batch", "replica": f"query-parallel x{world}: corpus replicated, {B} queries per GPU per step, no data-path collective"}[layout],
+                "space": args.space,
+                "parallelism": par,
                 "global_batch": B * (world if layout == "replica" else 1),
                 "mode": args.mode,
                 "shadow": shadow,
@@ -373,13 +474,30 @@ def main():
             "fallback_queries_per_batch": stats["fallback_queries"],
             "max_candidates": stats["max_candidates"],
         }
+        if world > 1:
+            line["rccl"] = {"ranks": world, "backend": "gloo (rehearsal)" if rehearsal else f"{backend} (RCCL)", "collective": "all_gather_into_tensor, one per batch, on its own stream" if layout == "shard" else None,
+                            "bytes_per_rank_per_batch": bytes_gathered if layout == "shard" else 0}
+        extras = {}
+        if replica is not None:
+            extras["replica_layout"] = replica
         if world == 1 and not args.no_extras:
-            line["extras"] = {"embed": bench_embed(eng, cpu_chunks=0 if args.no_cpu_baseline else 32), "exact_scan": bench_scan(eng, corpus, queries)}
-            line["extras"].update(bench_other_configs(eng))
+            from hybrid_rag_system_amd.dist import ShardedHybrid
+
+            extras["text_queries_end_to_end"] = bench_text_queries(eng, ShardedHybrid(eng, corpus, postings, group=False), n_keep)
+            extras["embed"] = bench_embed(eng, cpu_chunks=0 if args.no_cpu_baseline else 2048)
+            extras["exact_scan"] = bench_scan(eng, corpus, queries)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(matrix, terms, queries, q_terms, q_offs, n_keep, n_total, args.cpu_sample_rows, args.cpu_sample_queries)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            corpus.close()
+            postings.close()
+            del matrix, corpus, terms, postings
+            torch.cuda.empty_cache()
+            extras.update(bench_other_configs(eng))
+        if extras:
+            line["extras"] = extras
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

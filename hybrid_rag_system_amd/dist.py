@@ -67,13 +67,29 @@ def gather_rows(local_rows, n_total, group=None):
     return out.to(local_rows.device) if staged else out
 
 
+def _is_cuda(engine):
+    return getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
+
+
 class ShardedHybrid:
     """Hybrid top-n over a row-sharded corpus; every rank returns the same merged result.
     group=False: this rank holds the whole corpus (single GPU, or one replica of several) and no
-    exchange takes place even when a process group exists."""
+    exchange takes place even when a process group exists.
 
-    def __init__(self, engine, corpus, postings, group=None):
+    exchange_stream (a torch.cuda.Stream, optional): the exchange step -- all-gather of the per-shard
+    candidates, merge, fusion -- is enqueued there instead of on the stream of the scan, behind an event, so the
+    scan's stream is free for the next batch while the (latency-bound) collective is in flight.  The returned
+    tensors are then valid on that stream; `done_event` marks their completion."""
+
+    def __init__(self, engine, corpus, postings, group=None, exchange_stream=None):
         self.engine, self.corpus, self.postings, self.group = engine, corpus, postings, group
+        self.exchange_stream = exchange_stream
+        self.done_event = None
+        self._open = None
+        self.bytes_gathered = 0  # payload this rank contributed to the last exchange
+
+    def exchanges(self):
+        return self.group is not False and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def step(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
         self.begin(queries, q_terms, q_term_offs, n, boost, space, mode)
@@ -91,12 +107,44 @@ class ShardedHybrid:
         self._open = None
         _, rows, keys = e.score_topk_finish(want_keys=True)
         counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
-        if self.group is not False and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        cuda = _is_cuda(e)
+        xs = self.exchange_stream if (cuda and self.exchanges()) else None
+        if xs is not None:
+            ready = torch.cuda.Event()
+            ready.record()  # on the scan's stream: candidates and their counts are complete
+            for t in (keys, counts, q_term_offs):
+                t.record_stream(xs)  # allocated on the scan's stream, read on the exchange stream
+            with torch.cuda.stream(xs):
+                xs.wait_event(ready)
+                out = self._exchange_and_fuse(keys, counts, q_term_offs, n, boost)
+                self.done_event = torch.cuda.Event()
+                self.done_event.record()
+            return out
+        out = self._exchange_and_fuse(keys, counts, q_term_offs, n, boost)
+        if cuda:
+            self.done_event = torch.cuda.Event()
+            self.done_event.record()
+        return out
+
+    def _exchange_and_fuse(self, keys, counts, q_term_offs, n, boost):
+        e = self.engine
+        if self.exchanges():
+            self.bytes_gathered = keys.numel() * 16  # (key, count) as two int64 per candidate
             gk, gc = allgather_candidates(keys, counts, self.group)
             keys, counts = e.merge_topk(gk, gc)
         cand_dist, cand_rows = e.unpack_keys(keys)
         combined, perm = e.fuse_sort(cand_dist, counts, q_term_offs, n, boost)
         return {"cand_dist": cand_dist, "cand_rows": cand_rows, "cand_counts": counts, "combined": combined, "perm": perm}
+
+
+class _NoStream:
+    """Stands where a HIP stream would on an engine without one (CPU rehearsals of the pipeline's order of events)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class HybridPipeline:
@@ -107,14 +155,27 @@ class HybridPipeline:
     scattered row reads.  The scans take turns (hrs_ctx_set_peer); `submit` begins batch i + 1 on the
     next stream and only then enqueues the tail of batch i, which the library holds back until batch
     i + 1 has its thresholds: the tail then runs under the next main pass (both fit a CU's LDS and
-    registers together) instead of beside the sampled passes that precede it.  Every batch runs every
-    kernel of ShardedHybrid.step and results are identical.  `submit` returns the tensors of the
-    PREVIOUS batch (None for the first); `drain()` finishes the last one, waits for the streams on the
-    caller's stream and returns its tensors.
+    registers together) instead of beside the sampled passes that precede it.  On a row-sharded corpus the
+    exchange step of batch i (all-gather, merge, fusion) goes to a third stream of its own, so it too is in
+    flight under the scan of batch i + 1.  Every batch runs every kernel of ShardedHybrid.step and results
+    are identical.
+
+    Stream contract: `submit` orders the work behind whatever the caller's current stream has enqueued (the
+    inputs may have been produced there) and tells the allocator that they are in use on the pipeline's
+    streams, so the caller may drop them right after the call.  It returns the tensors of the PREVIOUS batch
+    (None for the first) after making the caller's current stream wait for them: they can be consumed there
+    without a device-wide synchronisation.  `drain()` finishes the last batch the same way.
     """
 
     def __init__(self, engines, corpus, postings, group=None):
-        self.lanes = [(ShardedHybrid(e, corpus, postings, group), torch.cuda.Stream(device=e.device)) for e in engines]
+        self.cuda = _is_cuda(engines[0])
+        mk = (lambda e: torch.cuda.Stream(device=e.device)) if self.cuda else (lambda e: None)
+        self.lanes = []
+        for e in engines:
+            searcher = ShardedHybrid(e, corpus, postings, group)
+            if self.cuda and searcher.exchanges():
+                searcher.exchange_stream = mk(e)
+            self.lanes.append((searcher, mk(e)))
         # the scans themselves take turns: each engine's scan waits for the previous engine's
         for j, e in enumerate(engines):
             if len(engines) > 1:
@@ -122,21 +183,34 @@ class HybridPipeline:
         self.n = 0
         self._open = None  # lane with a begun, unfinished batch
 
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if self.cuda else _NoStream()
+
     def _finish_open(self):
+        """Enqueue the tail of the open batch; the caller's stream then waits for its results."""
         if self._open is None:
             return None
         searcher, stream = self._open
         self._open = None
-        with torch.cuda.stream(stream):
-            return searcher.finish()
+        with self._on(stream):
+            out = searcher.finish()
+        if self.cuda:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(searcher.done_event)
+            for t in out.values():
+                t.record_stream(cur)  # allocated on a pipeline stream, consumed on the caller's
+        return out
 
     def submit(self, queries, q_terms, q_term_offs, n, **kw):
         searcher, stream = self.lanes[self.n % len(self.lanes)]
         self.n += 1
         if len(self.lanes) == 1:
             prev = self._finish_open()
-        stream.wait_stream(torch.cuda.current_stream())  # the inputs were produced on the caller's stream
-        with torch.cuda.stream(stream):
+        if self.cuda:
+            stream.wait_stream(torch.cuda.current_stream())  # the inputs were produced on the caller's stream
+            for t in (queries, q_terms, q_term_offs):
+                t.record_stream(stream)
+        with self._on(stream):
             searcher.begin(queries, q_terms, q_term_offs, n, **kw)
         if len(self.lanes) > 1:
             prev = self._finish_open()  # after the next scan has been enqueued
@@ -145,6 +219,9 @@ class HybridPipeline:
 
     def drain(self):
         last = self._finish_open()
-        for _, stream in self.lanes:
-            torch.cuda.current_stream().wait_stream(stream)
+        if self.cuda:
+            for searcher, stream in self.lanes:
+                torch.cuda.current_stream().wait_stream(stream)
+                if searcher.exchange_stream is not None:
+                    torch.cuda.current_stream().wait_stream(searcher.exchange_stream)
         return last

@@ -69,3 +69,102 @@ def test_shard_bounds_cover_everything():
             b = [shard_bounds(n, w, r) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+class _OracleEngine:
+    """The Engine interface over CPU tensors, every computation by the oracle: lets the shipped ShardedHybrid /
+    HybridPipeline (order of begin / finish / exchange, packing, merge bookkeeping) run under gloo without a GPU."""
+
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.peers = []
+
+    def set_peer(self, other):
+        self.peers.append(other)
+
+    def score_topk_begin(self, corpus, queries, k, space="l2", mask=None, mode="auto"):
+        self._call = (corpus, queries, k, space)
+
+    def score_topk_finish(self, want_keys=False):
+        (C, lo), q, k, space = self._call
+        keys = so.topk_keys(q.numpy(), C, k, space, row_offset=lo)
+        d, r = so.unpack(keys)
+        return torch.from_numpy(d), torch.from_numpy(r), torch.from_numpy(keys.view(np.int64))
+
+    def keyword_counts(self, postings, q_terms, q_term_offs, rows):
+        offs, terms, lo = postings
+        return torch.from_numpy(so.keyword_counts(offs, terms, q_term_offs.numpy(), q_terms.numpy(), rows.numpy(), row_offset=lo))
+
+    def merge_topk(self, keys, vals=None):
+        k = keys.numpy().view(np.uint64)
+        merged = so.merge(k)
+        lookup = {int(a): int(b) for a, b in zip(k.reshape(-1), vals.numpy().reshape(-1))}
+        mv = np.array([[lookup[int(x)] if x != so.PAD_KEY else 0 for x in row] for row in merged], np.int32)
+        return torch.from_numpy(merged.view(np.int64)), torch.from_numpy(mv)
+
+    def unpack_keys(self, keys):
+        d, r = so.unpack(keys.numpy().view(np.uint64))
+        return torch.from_numpy(d), torch.from_numpy(r)
+
+    def fuse_sort(self, dist, counts, q_term_offs, n, boost=0.3):
+        c, p, _, _ = so.fuse_sort(dist.numpy(), counts.numpy(), np.diff(q_term_offs.numpy()), n, boost)
+        return torch.from_numpy(c), torch.from_numpy(p)
+
+
+def _hybrid_inputs():
+    rng = np.random.default_rng(5)
+    n, d, V, L = 2003, 32, 60, 6
+    C = rng.standard_normal((n, d)).astype(np.float32)
+    terms = np.sort(rng.integers(0, V, (n, L)).astype(np.int32), axis=1)
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    batches = [rng.standard_normal((7, d)).astype(np.float32) for _ in range(4)]
+    m = rng.integers(0, 5, 7)
+    qoffs = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms = rng.integers(0, V, int(m.sum())).astype(np.int32)
+    return C, terms, offs, batches, qoffs, qterms
+
+
+def _pipeline_worker(rank, world, port, ret):
+    from hybrid_rag_system_amd.dist import HybridPipeline
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C, terms, offs, batches, qoffs, qterms = _hybrid_inputs()
+    lo, hi = shard_bounds(C.shape[0], world, rank)
+    L = terms.shape[1]
+    postings = (offs[: hi - lo + 1].copy(), terms[lo:hi].reshape(-1), lo)
+    engines = [_OracleEngine(), _OracleEngine()]
+    pipe = HybridPipeline(engines, (C[lo:hi], lo), postings)
+    assert engines[1].peers == [engines[0]] and engines[0].peers == [engines[1]]
+    outs = []
+    for q in batches:
+        prev = pipe.submit(torch.from_numpy(q), torch.from_numpy(qterms), torch.from_numpy(qoffs), 4)
+        if prev is not None:
+            outs.append(prev)  # batch i comes back from submit i + 1
+    outs.append(pipe.drain())
+    assert pipe.lanes[0][0].bytes_gathered == 7 * 8 * 16
+    ret[rank] = [{k: v.numpy() for k, v in o.items()} for o in outs]
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_hybrid_step_equals_unsharded():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pipeline_worker, args=(world, port, ret), nprocs=world, join=True)
+    C, terms, offs, batches, qoffs, qterms = _hybrid_inputs()
+    for r in range(world):
+        assert len(ret[r]) == len(batches)
+    for i, q in enumerate(batches):
+        keys = so.topk_keys(q, C, 8, "l2")
+        wd, wr = so.unpack(keys)
+        wcnt = so.keyword_counts(offs, terms.reshape(-1), qoffs, qterms, wr)
+        wc, wp, _, _ = so.fuse_sort(wd, wcnt, np.diff(qoffs), 4, 0.3)
+        for r in range(world):
+            o = ret[r][i]
+            assert np.array_equal(o["cand_rows"], wr) and np.array_equal(o["cand_dist"], wd)
+            assert np.array_equal(o["cand_counts"], wcnt) and np.array_equal(o["perm"], wp)
+            assert np.array_equal(o["combined"].view(np.uint64), wc.view(np.uint64))

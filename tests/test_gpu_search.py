@@ -399,6 +399,55 @@ def test_two_stream_pipeline_equals_single_stream(eng):
     corpus.close()
 
 
+def test_pipeline_results_are_consumable_on_the_callers_stream_without_a_device_sync(eng):
+    """The stream contract of HybridPipeline: what submit returns may be read on the caller's current stream at
+    once, and the inputs may be dropped right after submit -- no torch.cuda.synchronize() anywhere in the loop."""
+    from hybrid_rag_system_amd.dist import HybridPipeline, ShardedHybrid
+    from hybrid_rag_system_amd.engine import Engine
+
+    rng = np.random.default_rng(43)
+    n, d, b, keep, V, L = 400_000, 384, 512, 5, 500, 12
+    C = _unit(rng, n, d)
+    terms = np.sort(rng.integers(0, V, (n, L)).astype(np.int32), axis=1).reshape(-1)
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
+    m = rng.integers(1, 5, b)
+    qoffs_h = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms_h = rng.integers(0, V, int(m.sum())).astype(np.int32)
+    host = [_unit(rng, b, d) for _ in range(6)]
+    plain = ShardedHybrid(eng, corpus, post, group=False)
+    want = []
+    for q in host:
+        o = plain.step(torch.from_numpy(q).cuda(), torch.from_numpy(qterms_h).cuda(), torch.from_numpy(qoffs_h).cuda(), keep, mode="mfma")
+        torch.cuda.synchronize()
+        want.append({k: v.cpu() for k, v in o.items()})
+    eng2 = Engine(0)
+    pipe = HybridPipeline([eng, eng2], corpus, post, group=False)
+    side = torch.cuda.Stream()  # a caller that works on a stream of its own
+    copies = []
+    with torch.cuda.stream(side):
+        for q in host:
+            dq, dt, do = torch.from_numpy(q).cuda(), torch.from_numpy(qterms_h).cuda(), torch.from_numpy(qoffs_h).cuda()
+            prev = pipe.submit(dq, dt, do, keep, mode="mfma")
+            del dq, dt, do  # the allocator may hand these blocks out again: the pipeline has recorded its use of them
+            junk = torch.full((b, d), 3.0, device="cuda")  # ... for instance to this
+            if prev is not None:
+                copies.append({k: v + 0 for k, v in prev.items()})  # read on the caller's stream, no sync
+            del prev, junk
+        last = pipe.drain()
+        copies.append({k: v + 0 for k, v in last.items()})
+    torch.cuda.synchronize()
+    assert len(copies) == len(host)
+    for w, g in zip(want, copies):
+        for key in ("cand_rows", "cand_dist", "cand_counts", "perm", "combined"):
+            assert torch.equal(w[key], g[key].cpu()), key
+    eng.set_peer(None)
+    eng2.close()
+    corpus.close()
+    post.close()
+
+
 def test_two_phase_call_equals_single_call(eng):
     """hrs_score_topk_begin + _finish give what hrs_score_topk gives, whether the call can be split (matrix-core
     path, one chunk) or not (exact path, more than 1024 queries); one call may be open per context."""
