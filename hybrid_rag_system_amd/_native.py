@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhrs.so")
+LIB_PATH = os.environ.get("HRS_LIBRARY") or os.path.join(_HERE, "libhrs.so")  # HRS_LIBRARY: another build of the same ABI (A/B timing)
 
 SPACES = {"l2": 0, "cosine": 1, "ip": 2}
 SHADOWS = {"none": 0, "bf16": 1, "i8": 2, "auto": 3}

@@ -56,8 +56,18 @@ template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 // these kernels synchronise at every second boundary instead: four buffers, two tiles requested at a time.
 // 96 KB at depth 384, which leaves LDS for a re-score workgroup of the previous batch on the CU.
 constexpr bool scan_pairs(int qt) { return qt == 2; }
-constexpr int scan_nbuf(int tile_bytes, int qt) {
+// Rows above the threshold are staged in LDS, every wave in a region of its own with the fill level in a scalar
+// register (slots come from a ballot and a lane count: no atomic, no wait), and go to the per-query lists in
+// memory 64 at a time when the region is full.  Appending straight to memory makes every recording wave wait for
+// its atomic's return, i.e. for vmcnt(0): that drains the wave's share of the LDS-DMA ring and, through the tile
+// barrier, stalls all eight waves; over a small corpus (1M rows: a row above the threshold in every other 32 x 32
+// tile) that was half of the pass.
+constexpr int scan_stage(bool pair) { return pair ? 256 : 1024; }  // staged entries (12 bytes each)
+constexpr int scan_nbuf(int tile_bytes, int qt) {  // qt == 2 here means "the pair-wise schedule"
     return scan_pairs(qt) ? 4 : (tile_bytes * 5 <= HRS_SCAN_RING_BYTES ? 5 : (tile_bytes * 4 <= HRS_SCAN_RING_BYTES ? 4 : 3));
+}
+constexpr size_t scan_lds_bytes(int tile_bytes, bool pair) {
+    return (size_t)scan_nbuf(tile_bytes, pair ? 2 : 1) * tile_bytes + (size_t)scan_stage(pair) * 12;
 }
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
 #define MF_EPS_BASE 0.0039101
@@ -94,7 +104,12 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 
 // MODE 0: the whole corpus, rows above tau are recorded.  MODE 1: sampled tiles, per (query, stream)
 // running maximum.  MODE 2: sampled tiles, per query a 16-bin count of the scores above tau (the "ladder").
-template <int KS, int TR, int MODE, int QT, bool I8>
+// RS ("row split", batches of up to 256 queries on the kernels with two query tiles per wave): the eight waves are
+// four query groups of 64 x the two 32-row halves of a tile, instead of eight query groups of 32 that each read the
+// whole tile -- every corpus fragment read from LDS then feeds two MFMAs and a tile is read from LDS four times
+// instead of eight.  With one tile per wave the kernel is bound by LDS reads (8 waves x 24 KB per tile is all the
+// 128 B/clk an LDS delivers in the time the matrix cores need for the tile).
+template <int KS, int TR, int MODE, int QT, bool I8, bool RS = false>
 __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     constexpr bool PRE = MODE != 0;      // sampled pass
     constexpr bool MAXIMA = MODE == 1, LADDER = MODE == 2;
@@ -104,10 +119,13 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     constexpr int NW = 8;                     // waves per workgroup (256 * QT queries)
     constexpr int RB = KS * 32;               // row bytes
     constexpr int TILE_BYTES = TR * RB;
-    constexpr int NBUF = scan_nbuf(TILE_BYTES, QT);
-    constexpr bool PAIR = scan_pairs(QT);     // barrier at every second tile boundary
+    constexpr bool PAIR = scan_pairs(QT) && !RS;  // barrier at every second tile boundary
+    constexpr int NBUF = scan_nbuf(TILE_BYTES, PAIR ? 2 : 1);
     constexpr int IPW = TR * KS / (32 * NW);  // LDS-DMA instructions per wave per tile
-    constexpr int NSUB = TR / 32;
+    constexpr int NSUB = TR / 32;             // 32-row groups per tile (one int8 scale each)
+    constexpr int WSUB = RS ? 1 : NSUB;       // ... of which a wave scores this many
+    static_assert(!RS || (QT == 2 && NSUB == 2), "row split: two query tiles per wave, two row halves per tile");
+    constexpr int STG = scan_stage(PAIR);
     constexpr int PPR = 2 * KS;               // 16-byte pieces per row
     // Bank-conflict-free row reads need an XOR permutation of the pieces of a row that depends on the
     // row: 4 bits (r & 15) when the row is a multiple of 256 bytes, else 3 bits ((r >> 1) & 7) for rows
@@ -126,7 +144,8 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     const int qg = loc % a.nqg;
     const int nslices = HRS_NUM_CU / a.nqg;
     const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
-    const int q0 = qg * (MF_QPB * QT) + wv * MF_QPW;
+    const int sb0 = RS ? (wv >> 2) : 0;       // first 32-row group of a tile that this wave scores
+    const int q0 = RS ? qg * MF_QPB + (wv & 3) * MF_QPW : qg * (MF_QPB * QT) + wv * MF_QPW;
 
     frag_t qf[QT][KS];
 #pragma unroll
@@ -136,14 +155,14 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
             qf[qt][s] = *(const frag_t*)(a.qb + (size_t)(q0 + qt * 32 + i) * RB + s * 32 + h * 16);
 
     float tau[QT], kq[QT], linv[QT];
-    float mx[QT][NSUB];
+    float mx[QT][WSUB];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         tau[qt] = MAXIMA ? 0.f : a.tau[q0 + qt * 32 + i];
         kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
         linv[qt] = LADDER ? a.lad_inv[q0 + qt * 32 + i] : 0.f;
 #pragma unroll
-        for (int sb = 0; sb < NSUB; ++sb) mx[qt][sb] = -__builtin_inff();
+        for (int sb = 0; sb < WSUB; ++sb) mx[qt][sb] = -__builtin_inff();
     }
     // every query fragment must have landed before the loop: the compiler would otherwise place its
     // partial vmcnt waits at their first use inside the loop, where they would drain the LDS-DMA ring
@@ -186,7 +205,40 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     // SWB bits are ((2s) & mask) ^ v: NB per-lane bases, everything else is an immediate.
     int bc[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) bc[c] = (int)lds0 + i * RB + (((2 * c) ^ (h ^ (SWB == 4 ? (i & 15) : ((i >> 1) & 7)))) << 4);
+    for (int c = 0; c < NB; ++c) bc[c] = (int)lds0 + (sb0 * 32 + i) * RB + (((2 * c) ^ (h ^ (SWB == 4 ? (i & 15) : ((i >> 1) & 7)))) << 4);
+
+    // staged candidates (MODE 0): this wave's region of keys and of their queries
+    constexpr int WCAP = STG / NW;
+    uint64_t* const wk = (uint64_t*)(smem + NBUF * TILE_BYTES) + wv * WCAP;
+    uint32_t* const wq = (uint32_t*)((uint64_t*)(smem + NBUF * TILE_BYTES) + STG) + wv * WCAP;
+    int wcnt = 0;  // entries staged (wave-uniform)
+    auto to_memory = [&](uint64_t key, int q) __attribute__((always_inline)) {
+        if (!a.mask || a.mask[(int64_t)(uint32_t)key - a.row_offset]) {  // the `where` filter
+            const int pos = atomicAdd(&a.cnt[q], 1);
+            if (pos < HRS_CAND_CAP_BIG) a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] = key;
+        }
+    };
+    auto flush_wave = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) to_memory(wk[e], (int)wq[e]);
+        wcnt = 0;
+    };
+    // Lanes with `hit` record (key, q); every lane of the wave calls this (the ballot is the slot allocator).
+    auto record = [&](bool hit, uint64_t key, int q) __attribute__((always_inline)) {
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal == 0) return;
+        const int np = __builtin_popcountll(bal);
+        if (wcnt + np > WCAP) flush_wave();
+        const int slot = wcnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (hit) {
+            if (slot < WCAP) {
+                wk[slot] = key;
+                wq[slot] = (uint32_t)q;
+            } else {
+                to_memory(key, q);  // more hits in one instruction than the region holds
+            }
+        }
+        wcnt = __builtin_amdgcn_readfirstlane(min(wcnt + np, WCAP));
+    };
 
     if (count > 0) {
         typedef const __attribute__((address_space(3))) char* lds_cptr;
@@ -248,8 +300,11 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 }
                 scale_load(tile_at(n + 1));
             }
+            float2 scw[WSUB];  // the group terms of the 32-row groups this wave scores
 #pragma unroll
-            for (int sb = 0; sb < NSUB; ++sb) {
+            for (int sb = 0; sb < WSUB; ++sb) scw[sb] = RS ? (sb0 ? sc[NSUB - 1] : sc[0]) : sc[sb];
+#pragma unroll
+            for (int sb = 0; sb < WSUB; ++sb) {
                 acc_t acc[QT];
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
@@ -276,7 +331,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, QT * PF, 0);
-                if (sb + 1 < NSUB) {
+                if (sb + 1 < WSUB) {
 #pragma unroll
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
                 } else if (n + 1 < count) {
@@ -302,27 +357,27 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 }
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
-                    auto append = [&](int r, float score) __attribute__((always_inline)) {
-                        const int64_t row = tile * TR + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < a.N && (!a.mask || a.mask[row])) {
-                            const int q = q0 + qt * 32 + i;
-                            const int pos = atomicAdd(&a.cnt[q], 1);
-                            if (pos < HRS_CAND_CAP_BIG)
-                                a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] =
-                                    ((uint64_t)(~f32_orderable(score)) << 32) | (uint32_t)(row + a.row_offset);
-                        }
+                    // every lane calls this for every r of a 32 x 32 tile that holds a row above the threshold; all but
+                    // the compare and the ballot happen only for an r with such a row
+                    auto append = [&](bool hit, int r, auto&& score) __attribute__((always_inline)) {
+                        if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+                        const uint32_t row = (uint32_t)tile * TR + (sb0 + sb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        record(hit && row < (uint32_t)a.N, ((uint64_t)(~f32_orderable(score())) << 32) | (uint32_t)(row + (uint32_t)a.row_offset), q0 + qt * 32 + i);
                     };
                     if constexpr (I8) {
-                        int m = acc[qt][0];
+                        // maxima of the four groups of four rows, then of all sixteen: a tile with a row above the
+                        // threshold is searched group by group
+                        int m4[4];
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) m = max(m, acc[qt][r]);
+                        for (int g = 0; g < 4; ++g) m4[g] = max(max(acc[qt][4 * g], acc[qt][4 * g + 1]), max(acc[qt][4 * g + 2], acc[qt][4 * g + 3]));
+                        const int m = max(max(m4[0], m4[1]), max(m4[2], m4[3]));
                         if (MAXIMA) {
-                            mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + kq[qt] + sc[sb].y) * sc[sb].x);  // .x = s_g
+                            mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + kq[qt] + scw[sb].y) * scw[sb].x);  // .x = s_g
                         } else if (LADDER) {
-                            if (((float)m + kq[qt] + sc[sb].y) * sc[sb].x > tau[qt]) {
+                            if (((float)m + kq[qt] + scw[sb].y) * scw[sb].x > tau[qt]) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
-                                    const float v = ((float)acc[qt][r] + kq[qt] + sc[sb].y) * sc[sb].x;
+                                    const float v = ((float)acc[qt][r] + kq[qt] + scw[sb].y) * scw[sb].x;
                                     if (v > tau[qt]) atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + min(15, (int)((v - tau[qt]) * linv[qt]))], 1);
                                 }
                             }
@@ -330,17 +385,20 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                             // s_g (acc + K_q + M_g) > tau  <=>  acc > tau / s_g - K_q - M_g; the threshold is
                             // pushed down by more than the rounding of these few operations, so that no
                             // qualifying row is dropped
-                            float tf = tau[qt] * sc[sb].x;  // .x = 1 / s_g
+                            float tf = tau[qt] * scw[sb].x;  // .x = 1 / s_g
                             tf -= fabsf(tf) * 3e-7f;
-                            tf = tf - kq[qt] - sc[sb].y - 0.5f;
+                            tf = tf - kq[qt] - scw[sb].y - 0.5f;
                             const int ti = (int)floorf(fminf(fmaxf(tf, -2.1e9f), 2.1e9f));
-                            if (m > ti) {
+                            if (__builtin_amdgcn_ballot_w64(m > ti) != 0) {  // wave-uniform: some lane holds such a row
                                 // s_g again, from its reciprocal: no vector load may appear in this loop (its
                                 // wait would drain the DMA ring); the acceptance test allows for the rounding
-                                const float gs = 1.0f / sc[sb].x;
+                                const float gs = 1.0f / scw[sb].x;
 #pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    if (acc[qt][r] > ti) append(r, ((float)acc[qt][r] + kq[qt] + sc[sb].y) * gs);
+                                for (int g = 0; g < 4; ++g) {
+                                    if (__builtin_amdgcn_ballot_w64(m4[g] > ti) == 0) continue;
+#pragma unroll
+                                    for (int r = 4 * g; r < 4 * g + 4; ++r) append(acc[qt][r] > ti, r, [&]() { return ((float)acc[qt][r] + kq[qt] + scw[sb].y) * gs; });
+                                }
                             }
                         }
                     } else {
@@ -356,10 +414,9 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                                     if (acc[qt][r] > tau[qt])
                                         atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + min(15, (int)((acc[qt][r] - tau[qt]) * linv[qt]))], 1);
                             }
-                        } else if (m > tau[qt]) {
+                        } else if (__builtin_amdgcn_ballot_w64(m > tau[qt]) != 0) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                if (acc[qt][r] > tau[qt]) append(r, acc[qt][r]);
+                            for (int r = 0; r < 16; ++r) append(acc[qt][r] > tau[qt], r, [&]() { return acc[qt][r]; });
                         }
                     }
                 }
@@ -367,13 +424,14 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         }
         }  // waves with queries
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE == 0) flush_wave();  // what is still staged
     }
     if (MAXIMA) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int sb = 0; sb < NSUB; ++sb)
-                a.maxima[(size_t)(q0 + qt * 32 + i) * HRS_MAX_STREAMS + (slice * 2 + h) * NSUB + sb] = mx[qt][sb];
+            for (int sb = 0; sb < WSUB; ++sb)
+                a.maxima[(size_t)(q0 + qt * 32 + i) * HRS_MAX_STREAMS + (slice * 2 + h) * NSUB + sb0 + sb] = mx[qt][sb];
     }
 }
 
@@ -1184,22 +1242,22 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         for (int t = tid; t < a.k; t += 256) a.keys_out[(size_t)q * a.k + t] = ek[t];
 }
 
-template <int KS, int TR, bool I8, int QT>
+template <int KS, int TR, bool I8, int QT, bool RS>
 static int launch_scan_qt(const MfmaArgs& a, int mode, int device, hipStream_t st) {
-    const size_t lds = (size_t)scan_nbuf(TR * KS * 32, QT) * TR * KS * 32;
+    const size_t lds = scan_lds_bytes(TR * KS * 32, scan_pairs(QT) && !RS);
     static hrs_per_device_once attr;
     if (attr.need(device)) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 0, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 1, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 2, QT, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 0, QT, I8, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 1, QT, I8, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan<KS, TR, 2, QT, I8, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.done(device);
     }
     if (mode == 1)
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 1, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 1, QT, I8, RS>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     else if (mode == 2)
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 2, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 2, QT, I8, RS>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     else
-        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 0, QT, I8>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_mfma_scan<KS, TR, 0, QT, I8, RS>), dim3(HRS_NUM_CU), dim3(512), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
@@ -1209,11 +1267,15 @@ static int launch_scan_qt(const MfmaArgs& a, int mode, int device, hipStream_t s
 template <int KS, bool I8>
 constexpr int scan_qt_max() { return (I8 && KS <= 12) ? 2 : 1; }
 
+// qt: 1 one query tile per wave; 2 two; 3 two with the row split (batches of up to 256 queries)
 template <int KS, int TR, bool I8>
 static int launch_scan(MfmaArgs a, int mode, int qt, const hrs_corpus* c, int device, hipStream_t st) {
     a.group = mode == 0 ? c->group_main : c->group_pre;
-    if (qt == 2 && scan_qt_max<KS, I8>() == 2) return launch_scan_qt<KS, TR, I8, scan_qt_max<KS, I8>()>(a, mode, device, st);
-    return launch_scan_qt<KS, TR, I8, 1>(a, mode, device, st);
+    if constexpr (scan_qt_max<KS, I8>() == 2 && TR == 64) {
+        if (qt == 3) return launch_scan_qt<KS, TR, I8, 2, true>(a, mode, device, st);
+        if (qt == 2) return launch_scan_qt<KS, TR, I8, 2, false>(a, mode, device, st);
+    }
+    return launch_scan_qt<KS, TR, I8, 1, false>(a, mode, device, st);
 }
 
 template <int SPACE>
@@ -1294,8 +1356,9 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         const int bc = B - qbase < BC ? B - qbase : BC;
         const int bpad = (wide && bc <= 128) ? 128 : (bc <= 256 ? 256 : (bc <= 512 ? 512 : 1024));
         // 64 queries per wave for large batches on the shallow int8 kernels
-        const int qt = (i8 && KS <= 12 && bpad >= 512 && !ctx->scan_qt1) ? 2 : 1;
-        const int nqg = bpad / (wide ? 128 : MF_QPB * qt);
+        // on the shallow int8 kernels: 64 queries per wave; batches of up to 256 split the rows of a tile as well
+        const int qt = (i8 && KS <= 12 && !ctx->scan_qt1) ? (bpad >= 512 ? 2 : 3) : 1;
+        const int nqg = bpad / (wide ? 128 : MF_QPB * (qt == 2 ? 2 : 1));
         const int nslices = HRS_NUM_CU / nqg;
         // cleared by the convert kernel: this chunk's deferred-queue length; for the first chunk also the
         // fallback-queue length and the call's statistics
