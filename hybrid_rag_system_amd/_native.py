@@ -44,6 +44,10 @@ EXPORTS = [
     "hrs_postings_register",
     "hrs_postings_release",
     "hrs_keyword_counts",
+    "hrs_postings_register_inverted",
+    "hrs_postings_release_inverted",
+    "hrs_match_counts",
+    "hrs_score_topk_levels",
     "hrs_fuse_sort",
     "hrs_merge_topk",
     "hrs_unpack_keys",
@@ -102,6 +106,10 @@ def lib():
             "hrs_row_mask_update": ([vp, i64, vp, vp, i32, i32, vp, i32, vp, vp], i32),
             "hrs_postings_register": ([vp, vp, vp, i64, i64, C.POINTER(vp)], i32),
             "hrs_postings_release": ([vp, vp], i32),
+            "hrs_postings_register_inverted": ([vp, vp, vp, i64, i64, C.POINTER(vp)], i32),
+            "hrs_postings_release_inverted": ([vp, vp], i32),
+            "hrs_match_counts": ([vp, vp, vp, vp, i32, i64, vp, vp], i32),
+            "hrs_score_topk_levels": ([vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp], i32),
             "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),
             "hrs_fuse_sort": ([vp, vp, vp, vp, i32, i32, dbl, i32, vp, vp, vp], i32),
             "hrs_merge_topk": ([vp, vp, vp, i32, i32, i32, vp, vp, vp], i32),

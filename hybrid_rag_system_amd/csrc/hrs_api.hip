@@ -205,6 +205,24 @@ extern "C" int hrs_score_topk_after(hrs_ctx* ctx, hrs_corpus* c, const float* Q_
     return rc;
 }
 
+extern "C" int hrs_score_topk_levels(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
+                                     const uint8_t* level_dev, int64_t row_pitch, int levels, uint64_t* keys_dev, void* stream) {
+    int rc = check_topk_args("hrs_score_topk_levels", ctx, c, Q_dev, B, k, space, HRS_MODE_EXACT);
+    if (rc) return rc;
+    HRS_REQUIRE(level_dev && keys_dev, "hrs_score_topk_levels: null argument");
+    HRS_REQUIRE(levels >= 1 && levels <= 256 && row_pitch >= c->N, "hrs_score_topk_levels: levels=%d, row_pitch=%lld", levels,
+                (long long)row_pitch);
+    if (B == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    // one masked pass per level: the rows whose byte equals the level, each query under its own mask
+    for (int l = 0; l < levels; ++l) {
+        rc = hrs_launch_exact(ctx, c, Q_dev, B, k, space, level_dev, nullptr, nullptr, keys_dev + (size_t)l * k, (hipStream_t)stream,
+                              nullptr, row_pitch, l, (int64_t)levels * k);
+        if (rc) return rc;
+    }
+    return HRS_OK;
+}
+
 extern "C" int hrs_corpus_release(hrs_ctx* ctx, hrs_corpus* c) {
     if (!c) return HRS_OK;
     if (ctx) (void)hipSetDevice(ctx->device);

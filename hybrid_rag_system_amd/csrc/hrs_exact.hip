@@ -41,6 +41,8 @@ struct ExactArgs {
     int nq;
     int k;
     const uint8_t* mask;
+    int64_t mask_qstride;   // 0: one mask for all queries; else query q reads mask[q * mask_qstride + row]
+    int mask_eq;            // < 0: a row is kept when its mask byte is non-zero; else when it equals this value
     const uint64_t* after;  // nullable, per query: only keys strictly above it are eligible (a search resumed behind its last result)
     uint64_t* partial;  // [nq][gridDim.x][k]
     int64_t tiles;
@@ -201,12 +203,16 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                 const int64_t tile = tile_begin + step / nchunks;
                 const int64_t row = tile * ER + row_t;
                 bool live = row < a.N && qslot < NSL;
-                if (live && a.mask) live = a.mask[row] != 0;
+                if (live && a.mask && a.mask_qstride == 0) live = a.mask_eq < 0 ? a.mask[row] != 0 : a.mask[row] == a.mask_eq;
                 if (live) {
                     const uint32_t grow = (uint32_t)(row + a.row_offset);
 #pragma unroll
                     for (int b = 0; b < NQT; ++b) {
                         const int qb_i = qslot + NSL * b;
+                        if (a.mask_qstride) {  // a mask per query (rows grouped by their keyword match count)
+                            const uint8_t mv = a.mask[(int64_t)qidx[qb_i] * a.mask_qstride + row];
+                            if (a.mask_eq < 0 ? mv == 0 : mv != a.mask_eq) continue;
+                        }
                         double d;
                         if (SPACE == HRS_SPACE_L2) {
                             d = acc[b];
@@ -271,6 +277,7 @@ struct MergeArgs {
     int k;
     const int32_t* qlist;  // final level only: scatter to out[qlist[q]]
     int final_level;
+    int64_t out_stride;    // final level: keys of query q go to out + q * out_stride (k when the lists are dense)
 };
 
 __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
     bitonic_sort_u64(s, n2, threadIdx.x, 256);
     uint64_t* dst;
     if (a.final_level)
-        dst = a.out + (size_t)(a.qlist ? a.qlist[q] : q) * a.k;
+        dst = a.out + (size_t)(a.qlist ? a.qlist[q] : q) * a.out_stride;
     else
         dst = a.out + ((size_t)q * ngroups + g) * a.k;
     for (int i = threadIdx.x; i < a.k; i += 256) dst[i] = i < n2 ? s[i] : HRS_PAD_KEY;
@@ -322,7 +329,8 @@ static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipS
 // [B][ceil(grid/16)][k]; every word that is read has been written by this call.
 static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, uint64_t* p0, int grid, bool timed,
-                     hipStream_t st, const uint64_t* after = nullptr) {
+                     hipStream_t st, const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1,
+                     int64_t out_stride = 0) {
     const int64_t tiles = (c->N + ER - 1) / ER;
     const int per = 16;
     const int g1 = (grid + per - 1) / per;
@@ -340,6 +348,8 @@ static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     a.nq = B;
     a.k = k;
     a.mask = mask;
+    a.mask_qstride = mask_qstride;
+    a.mask_eq = mask_eq;
     a.after = after;
     a.partial = p0;
     a.tiles = tiles;
@@ -368,6 +378,7 @@ static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     m.k = k;
     m.per = per;
     m.qlist = qlist;
+    m.out_stride = out_stride ? out_stride : k;
     if (g1 > 1) {
         m.in = p0;
         m.out = p1;
@@ -399,12 +410,14 @@ static size_t exact_scratch_words(int B, int grid, int k) {
 }
 
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st, const uint64_t* after) {
+                     const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st, const uint64_t* after,
+                     int64_t mask_qstride, int mask_eq, int64_t out_stride) {
     if (B <= 0) return HRS_OK;
     const int grid = exact_grid(ctx, c);
     int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, exact_scratch_words(B, grid, k) * sizeof(uint64_t));
     if (rc) return rc;
-    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st, after);
+    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st, after,
+                     mask_qstride, mask_eq, out_stride);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------------

@@ -1,4 +1,6 @@
 // Keyword presence counts over forward-CSR postings, score fusion + stable order, cross-shard merge.
+#include <new>
+
 #include "hrs_internal.h"
 
 // One wave per (query, candidate): the 64 lanes read the row's term list coalesced and compare each
@@ -216,6 +218,70 @@ extern "C" int hrs_row_mask_update(hrs_ctx* ctx, int64_t N, const int32_t* codes
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_row_mask_update, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, codes_dev,
                        values_dev, m, negate, other_dev, combine, mask_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+// ---- full-corpus keyword side: inverted CSR postings -------------------------------------------------
+// counts[b][row] = how many of query b's terms occur in `row`, for EVERY row: the posting list of each query term
+// is streamed (coalesced reads of ascending rows) and the row's byte is incremented.  A row occurs at most once in
+// a term's list, but two terms of a query may meet in one row from different workgroups: the increment is a 32-bit
+// atomic on the word that holds the byte (counts stay below 256, so no carry crosses a byte).
+__global__ __launch_bounds__(256) void k_match_counts(const int64_t* __restrict__ term_offs, const int32_t* __restrict__ doc_ids,
+                                                      int64_t V, int64_t N, const int32_t* __restrict__ q_terms,
+                                                      const int32_t* __restrict__ q_term_offs, uint8_t* __restrict__ counts) {
+    const int b = blockIdx.y;
+    uint32_t* row0 = (uint32_t*)(counts + (int64_t)b * N);  // N is a multiple of 4 here (the caller pads the row pitch)
+    for (int t = q_term_offs[b]; t < q_term_offs[b + 1]; ++t) {
+        const int term = q_terms[t];
+        if (term < 0 || term >= V) continue;
+        const int64_t p0 = term_offs[term], p1 = term_offs[term + 1];
+        for (int64_t p = p0 + (int64_t)blockIdx.x * 256 + threadIdx.x; p < p1; p += (int64_t)gridDim.x * 256) {
+            const int32_t r = doc_ids[p];
+            atomicAdd(row0 + (r >> 2), 1u << (8 * (r & 3)));
+        }
+    }
+}
+
+extern "C" int hrs_postings_register_inverted(hrs_ctx* ctx, const int64_t* term_offs_dev, const int32_t* doc_ids_dev, int64_t V,
+                                              int64_t N, hrs_inverted** out) {
+    HRS_REQUIRE(ctx && out && term_offs_dev, "hrs_postings_register_inverted: null argument");
+    HRS_REQUIRE(V >= 0 && N >= 0 && N < (1ll << 31), "hrs_postings_register_inverted: bad size");
+    hrs_inverted* p = new (std::nothrow) hrs_inverted();
+    if (!p) {
+        hrs_set_error("hrs_postings_register_inverted: out of host memory");
+        return HRS_ERR_NOMEM;
+    }
+    p->term_offs = term_offs_dev;
+    p->doc_ids = doc_ids_dev;
+    p->V = V;
+    p->N = N;
+    *out = p;
+    return HRS_OK;
+}
+
+extern "C" int hrs_postings_release_inverted(hrs_ctx* ctx, hrs_inverted* p) {
+    (void)ctx;
+    delete p;
+    return HRS_OK;
+}
+
+extern "C" int hrs_match_counts(hrs_ctx* ctx, hrs_inverted* p, const int32_t* q_terms_dev, const int32_t* q_term_offs_dev, int B,
+                                int64_t row_pitch, uint8_t* counts_dev, void* stream) {
+    HRS_REQUIRE(ctx && p && q_term_offs_dev && counts_dev, "hrs_match_counts: null argument");
+    HRS_REQUIRE(B >= 0 && B <= 65535, "hrs_match_counts: B=%d outside [0, 65535]", B);
+    HRS_REQUIRE(row_pitch >= p->N && row_pitch % 4 == 0 && ((uintptr_t)counts_dev & 3) == 0,
+                "hrs_match_counts: row_pitch=%lld must be a multiple of 4 that holds the %lld rows (and counts_dev 4-byte aligned)",
+                (long long)row_pitch, (long long)p->N);
+    if (B == 0 || p->N == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    HRS_CHECK_HIP(hipMemsetAsync(counts_dev, 0, (size_t)B * row_pitch, st));
+    // enough workgroups per query to stream a long posting list at full bandwidth, few enough that short ones cost little
+    int gx = (int)((p->N / 256 / 8) < 1 ? 1 : (p->N / 256 / 8));
+    if (gx > 1024 / (B < 4 ? 1 : 4)) gx = 1024 / (B < 4 ? 1 : 4);
+    hipLaunchKernelGGL(k_match_counts, dim3(gx, B), dim3(256), 0, st, p->term_offs, p->doc_ids, p->V, row_pitch, q_terms_dev,
+                       q_term_offs_dev, counts_dev);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }

@@ -100,6 +100,12 @@ struct hrs_corpus {
     double* norm_stats = nullptr;  // owned: {min |c|^2, max |c|^2} as doubles
 };
 
+struct hrs_inverted {
+    const int64_t* term_offs = nullptr;  // [V + 1]
+    const int32_t* doc_ids = nullptr;    // [nnz] local rows of this shard, ascending within a term
+    int64_t V = 0, N = 0;
+};
+
 struct hrs_postings {
     const int64_t* doc_offs = nullptr;
     const int32_t* term_ids = nullptr;
@@ -184,7 +190,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 // Launchers implemented in the kernel files.
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st,
-                     const uint64_t* after = nullptr);
+                     const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1, int64_t out_stride = 0);
 // phase: HRS_PHASE_ALL the whole call; HRS_PHASE_SCAN up to and including the main pass (B <= 1024);
 // HRS_PHASE_TAIL the rest of a call whose scan phase ran with the same arguments
 enum { HRS_PHASE_ALL = 0, HRS_PHASE_SCAN = 1, HRS_PHASE_TAIL = 2 };

@@ -101,6 +101,44 @@ class Postings:
             pass
 
 
+class InvertedPostings:
+    """Inverted CSR of one shard: rows of term t are doc_ids[term_offs[t] : term_offs[t + 1]] (keeps both tensors alive)."""
+
+    def __init__(self, engine, term_offs, doc_ids, n_rows):
+        if not (term_offs.is_cuda and term_offs.dtype == torch.int64 and term_offs.is_contiguous()):
+            raise ValueError("term_offs must be a contiguous int64 CUDA tensor")
+        if not (doc_ids.is_cuda and doc_ids.dtype == torch.int32 and doc_ids.is_contiguous()):
+            raise ValueError("doc_ids must be a contiguous int32 CUDA tensor")
+        self.engine, self.term_offs, self.doc_ids = engine, term_offs, doc_ids
+        self.vocab, self.n = term_offs.numel() - 1, int(n_rows)
+        h = C.c_void_p()
+        N.check(N.lib().hrs_postings_register_inverted(engine._ctx, _ptr(term_offs), _ptr(doc_ids), self.vocab, self.n, C.byref(h)), "hrs_postings_register_inverted")
+        self._h = h
+
+    @classmethod
+    def from_forward(cls, engine, doc_offs, term_ids, vocab):
+        """Build the inverted lists from forward CSR term lists (torch sorting as plumbing: an index build, not a query path)."""
+        n = doc_offs.numel() - 1
+        rows = torch.repeat_interleave(torch.arange(n, device=term_ids.device, dtype=torch.int32), (doc_offs[1:] - doc_offs[:-1]))
+        key = term_ids.to(torch.int64) * n + rows.to(torch.int64)
+        key = torch.unique(key)  # sorted; a term listed twice in a row counts once
+        terms, docs = key // n, (key % n).to(torch.int32)
+        offs = torch.zeros(vocab + 1, dtype=torch.int64, device=term_ids.device)
+        offs[1:] = torch.cumsum(torch.bincount(terms, minlength=vocab), 0)
+        return cls(engine, offs.contiguous(), docs.contiguous(), n)
+
+    def close(self):
+        if self._h is not None:
+            N.lib().hrs_postings_release_inverted(self.engine._ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Encoder:
     """MiniLM-class encoder resident on the GPU (owns its weight copies)."""
 
@@ -170,6 +208,9 @@ class Engine:
 
     def postings(self, doc_offs, term_ids, row_offset=0):
         return Postings(self, doc_offs, term_ids, row_offset)
+
+    def inverted_postings(self, term_offs, doc_ids, n_rows):
+        return InvertedPostings(self, term_offs, doc_ids, n_rows)
 
     def encoder(self, weights, cfg):
         return Encoder(self, weights, cfg)
@@ -271,6 +312,57 @@ class Engine:
             "hrs_fuse_sort",
         )
         return combined, perm
+
+    def match_counts(self, inverted, q_terms, q_term_offs, B):
+        """-> uint8 [B, pitch] (pitch = rows rounded up to 4): per query, how many of its terms every row holds."""
+        pitch = (inverted.n + 3) // 4 * 4
+        counts = torch.empty((B, pitch), dtype=torch.uint8, device=self.device)
+        N.check(N.lib().hrs_match_counts(self._ctx, inverted._h, _ptr(q_terms), _ptr(q_term_offs), B, pitch, _ptr(counts), _stream()), "hrs_match_counts")
+        return counts
+
+    def score_topk_levels(self, corpus, queries, k, levels, level_of_row, space="l2"):
+        """level_of_row uint8 [B, pitch] -> keys int64 (uint64 bits) [B, levels, k]: exact top-k within every level."""
+        B = queries.shape[0]
+        keys = torch.empty((B, levels, k), dtype=torch.int64, device=self.device)
+        N.check(
+            N.lib().hrs_score_topk_levels(self._ctx, corpus._h, _ptr(queries), B, k, N.SPACES[space], _ptr(level_of_row), level_of_row.shape[1], levels, _ptr(keys), _stream()),
+            "hrs_score_topk_levels",
+        )
+        return keys
+
+    def hybrid_full_corpus(self, corpus, inverted, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", max_terms=None, chunk_bytes=4 << 30):
+        """Full-corpus hybrid mode (an extension; the reference's behaviour is hybrid_topk): the n best rows of the
+        WHOLE shard under the fused score of scripts/chromadb_helper.py:302-325 (keyword fraction over term ids),
+        ties by (distance, row).  Exact: the best n of every match-count class 0..m by distance contain the best n
+        overall.  Queries are processed in chunks whose [chunk, rows] count matrix fits `chunk_bytes`.
+        -> dict(rows int64 [B,n], dist fp32 [B,n], counts int32 [B,n], combined fp64 [B,n])."""
+        B = queries.shape[0]
+        if max_terms is None:
+            max_terms = int((q_term_offs[1:] - q_term_offs[:-1]).max().item()) if B else 0
+        levels = max_terms + 1
+        if levels * n > 256:
+            raise ValueError(f"(max query terms + 1) * n = {levels * n} candidates per query exceed 256")
+        out = {"rows": [], "dist": [], "counts": [], "combined": []}
+        step = max(1, min(B, chunk_bytes // max(1, corpus.n)))
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            qo = (q_term_offs[b0 : b1 + 1] - q_term_offs[b0 : b0 + 1]).contiguous()
+            qt = q_terms[int(q_term_offs[b0].item()) :]
+            if qt.numel() == 0:
+                qt = torch.zeros(1, dtype=torch.int32, device=self.device)
+            counts = self.match_counts(inverted, qt, qo, b1 - b0)
+            keys = self.score_topk_levels(corpus, queries[b0:b1].contiguous(), n, levels, counts, space)
+            lv = torch.arange(levels, dtype=torch.int32, device=self.device).view(1, levels, 1).expand(b1 - b0, levels, n).contiguous()
+            skeys, scnt = self.merge_topk(keys.view(1, b1 - b0, levels * n), lv.view(1, b1 - b0, levels * n))  # all candidates, nearest first
+            dist, rows = self.unpack_keys(skeys)
+            combined, perm = self.fuse_sort(dist, scnt, qo, n, boost)
+            idx = perm.clamp(min=0).to(torch.int64)
+            miss = perm < 0
+            out["rows"].append(torch.gather(rows, 1, idx).masked_fill(miss, -1))
+            out["dist"].append(torch.gather(dist, 1, idx).masked_fill(miss, float("inf")))
+            out["counts"].append(torch.gather(scnt, 1, idx).masked_fill(miss, 0))
+            out["combined"].append(combined)
+        return {k: torch.cat(v) for k, v in out.items()}
 
     def merge_topk(self, keys, vals=None):
         """keys int64(uint64 bits) [G,B,k] (+ vals int32 [G,B,k]) -> best k per query."""

@@ -118,12 +118,21 @@ def _fuse(documents, metadatas, ids, distances, keywords, n_results, keyword_boo
     return scored[:n_results]
 
 
-def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.3):
+def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.3, full_corpus=None):
     """Semantic top-2n re-ranked with the keyword fraction (scripts/chromadb_helper.py:275-325).
-    Like the reference it does not catch exceptions and ignores any `where` filter."""
+    Like the reference it does not catch exceptions and ignores any `where` filter.
+
+    full_corpus (default: the environment's HRS_HYBRID_FULL == "1", i.e. off) switches to an EXTENSION the reference
+    does not have: the same fused score, but its n best over the whole collection instead of over the 2n nearest
+    rows -- a document that contains every keyword is found even when it is not among the 2n nearest."""
     collection = get_collection(collection_name)
-    res = collection.query(query_texts=[query_text], n_results=n_results * 2, include=["documents", "metadatas", "distances"])
     keywords = extract_keywords(query_text)
+    if full_corpus is None:
+        full_corpus = os.getenv("HRS_HYBRID_FULL") == "1"
+    if full_corpus and keywords:
+        res = collection.query_keyword_classes([query_text], [keywords], n_results, include=["documents", "metadatas", "distances"])
+    else:
+        res = collection.query(query_texts=[query_text], n_results=n_results * 2, include=["documents", "metadatas", "distances"])
     if not (res.get("documents") and res["documents"][0]):
         return []
     return _fuse(

@@ -99,3 +99,6 @@ class RemoteCollection:
         return self._client.call(
             "query", name=self.name, query_texts=query_texts, n_results=n_results, include=include, where=where, query_embeddings=query_embeddings
         )
+
+    def query_keyword_classes(self, query_texts, keywords, n_results=10, include=None):
+        return self._client.call("query_keyword_classes", name=self.name, query_texts=list(query_texts), keywords=[list(k) for k in keywords], n_results=n_results, include=include)

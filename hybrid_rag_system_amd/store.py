@@ -457,6 +457,55 @@ class Collection:
                 res["distances"].append([float(dist[b][j]) for j in range(len(rr))])
         return res
 
+    def query_keyword_classes(self, query_texts, keywords, n_results=10, include=None):
+        """For the full-corpus hybrid mode (an extension, not reference behaviour): per query, the n_results nearest
+        rows of EVERY keyword-match class -- class c holds the documents that contain exactly c of the query's
+        `keywords[b]` as substrings of the lower-cased text, the test of scripts/chromadb_helper.py:352-359 -- merged
+        nearest first.  Within a class the fused score of scripts/chromadb_helper.py:310 falls as the distance grows,
+        so these (m + 1) * n_results rows contain the n_results best of the whole collection; the caller fuses them
+        exactly as it fuses the 2n nearest.  Same result shape as query()."""
+        include = list(include) if include is not None else ["documents", "metadatas", "distances"]
+        eng = engine()
+        texts = list(query_texts)
+        q = self._ef.embed_tensor(texts) if hasattr(self._ef, "embed_tensor") else torch.tensor(self._ef(texts), dtype=torch.float32, device=eng.device)
+        res = {"ids": [], "documents": [] if "documents" in include else None, "metadatas": [] if "metadatas" in include else None, "distances": [] if "distances" in include else None}
+        n = self.count()
+        k = min(int(n_results), n, MAX_K)
+        if n == 0 or k <= 0:
+            for _ in texts:
+                for key in res:
+                    if res[key] is not None:
+                        res[key].append([])
+            return res
+        low = getattr(self, "_lower_docs", None)
+        if low is None or len(low) != n:
+            low = self._lower_docs = [(d or "").lower() for d in self.documents]
+        pitch = (n + 3) // 4 * 4
+        cls = np.zeros((len(texts), pitch), np.uint8)
+        levels = 1
+        for b, kws in enumerate(keywords):
+            kws = list(kws)[:255]
+            levels = max(levels, len(kws) + 1)
+            if kws:
+                cls[b, :n] = np.fromiter((sum(1 for kw in kws if kw in d) for d in low), np.uint8, n)
+        corpus = self._resident()
+        keys = eng.score_topk_levels(corpus, q.contiguous(), k, levels, torch.from_numpy(cls).to(eng.device), space=self.space)
+        if levels * k > 2048:
+            raise ValueError(f"(keywords + 1) * n_results = {levels * k} candidates per query exceed 2048")
+        merged = eng.merge_topk(keys.view(1, len(texts), levels * k))  # all classes, nearest first
+        dist, rows = eng.unpack_keys(merged)
+        rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
+        for b in range(len(texts)):
+            rr = [int(x) for x in rows[b] if x >= 0]
+            res["ids"].append([self.ids[x] for x in rr])
+            if res["documents"] is not None:
+                res["documents"].append([self.documents[x] for x in rr])
+            if res["metadatas"] is not None:
+                res["metadatas"].append([self.metadatas[x] for x in rr])
+            if res["distances"] is not None:
+                res["distances"].append([float(dist[b][j]) for j in range(len(rr))])
+        return res
+
     def _topk_beyond_max(self, q, k, mask):
         """More results than one scan returns (n_results is unbounded in the reference): passes of MAX_K for the
         whole batch, each resumed behind the last key every query has received (hrs_score_topk_after).  The order

@@ -32,6 +32,7 @@ extern "C" {
 typedef struct hrs_ctx hrs_ctx;
 typedef struct hrs_corpus hrs_corpus;
 typedef struct hrs_postings hrs_postings;
+typedef struct hrs_inverted hrs_inverted;
 typedef struct hrs_encoder hrs_encoder;
 
 enum hrs_status {
@@ -234,6 +235,26 @@ int hrs_keyword_counts(hrs_ctx* ctx, hrs_postings* p, const int32_t* q_terms_dev
  * (-1 when missing).  c <= 2 * HRS_MAX_K. */
 int hrs_fuse_sort(hrs_ctx* ctx, const float* dist_dev, const int32_t* counts_dev, const int32_t* q_term_offs_dev,
                   int B, int c, double boost, int n, double* combined_dev, int32_t* perm_dev, void* stream);
+
+/* ---- full-corpus hybrid mode (an extension: NOT what the reference computes) ------------------------ */
+/* The reference re-ranks the 2n nearest rows (scripts/chromadb_helper.py:289-325); these entry points fuse the keyword
+ * fraction of scripts/chromadb_helper.py:352-359 with the semantic score over EVERY row instead, exactly: within the
+ * rows that match the same number c of a query's terms the fused score falls as the distance grows, so the best n of
+ * each class c = 0 .. m (by distance, then row) contain the best n overall.
+ *
+ * Inverted CSR of this shard: the rows that hold term t are doc_ids_dev[term_offs_dev[t] .. term_offs_dev[t+1])
+ * (local rows, each at most once per term); the handle keeps both pointers. */
+int hrs_postings_register_inverted(hrs_ctx* ctx, const int64_t* term_offs_dev, const int32_t* doc_ids_dev, int64_t V,
+                                   int64_t N, hrs_inverted** out);
+int hrs_postings_release_inverted(hrs_ctx* ctx, hrs_inverted* p);
+/* counts_dev uint8 [B, row_pitch] (row_pitch >= N, a multiple of 4): counts_dev[b][r] = how many of query b's terms
+ * (distinct, fewer than 256) occur in local row r -- the numerator of calculate_keyword_score for every row. */
+int hrs_match_counts(hrs_ctx* ctx, hrs_inverted* p, const int32_t* q_terms_dev, const int32_t* q_term_offs_dev, int B,
+                     int64_t row_pitch, uint8_t* counts_dev, void* stream);
+/* keys_dev uint64 [B, levels, k]: for every query and every l < levels the exact top-k (as hrs_score_topk, exact
+ * streaming scan) among the rows with level_dev[b * row_pitch + r] == l. */
+int hrs_score_topk_levels(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
+                          const uint8_t* level_dev, int64_t row_pitch, int levels, uint64_t* keys_dev, void* stream);
 
 /* ---- cross-shard merge (no counterpart in the single-process reference) -------------------- */
 /* keys_dev uint64 [G, B, k]: per-shard results gathered from G ranks (all-gather over RCCL is done

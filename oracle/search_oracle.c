@@ -306,3 +306,67 @@ void hrs_oracle_fuse_sort(const float* dist, const int32_t* counts, const int32_
     free(comb);
     free(idx);
 }
+
+/*
+ * Full-corpus hybrid mode -- an EXTENSION with no counterpart in the reference (which fuses only the 2n nearest
+ * rows, scripts/chromadb_helper.py:289-325): PARITY UNPINNED by construction.  Brute force over every row: the
+ * reported fp32 distance, the keyword fraction of scripts/chromadb_helper.py:352-359 over integer term ids (forward
+ * CSR), the fused score in the arithmetic of hrs_oracle_fuse_sort, then the n best under
+ * (fused score descending, distance key ascending) -- what a stable descending sort of ALL rows, listed nearest first,
+ * would keep.  out_rows / out_combined / out_counts [B][n]; missing entries -1 / -1.0 / 0.
+ */
+typedef struct {
+    double comb;
+    uint64_t key;
+    int32_t cnt;
+} full_item;
+
+static int full_better(const full_item* a, const full_item* b) { /* does a come before b */
+    if (a->comb != b->comb) return a->comb > b->comb;
+    return a->key < b->key;
+}
+
+void hrs_oracle_hybrid_full(const float* Q, const float* C, int64_t N, int D, int B, int space, const int64_t* doc_offs,
+                            const int32_t* term_ids, const int32_t* q_term_offs, const int32_t* q_terms, int n, double boost,
+                            int64_t* out_rows, double* out_combined, int32_t* out_counts, float* out_dist) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        full_item* best = (full_item*)malloc(sizeof(full_item) * (size_t)(n > 0 ? n : 1));
+        int have = 0;
+        const int m = q_term_offs[b + 1] - q_term_offs[b];
+        for (int64_t r = 0; r < N; ++r) {
+            full_item it;
+            it.key = hrs_oracle_key(Q + (size_t)b * D, C + (size_t)r * D, D, space, (uint32_t)r);
+            it.cnt = 0;
+            for (int32_t t = q_term_offs[b]; t < q_term_offs[b + 1]; ++t)
+                for (int64_t p = doc_offs[r]; p < doc_offs[r + 1]; ++p)
+                    if (term_ids[p] == q_terms[t]) {
+                        ++it.cnt;
+                        break;
+                    }
+            const double d = (double)orderable_f32((uint32_t)(it.key >> 32));
+            double sem = 1.0 - d;
+            if (!(sem > 0.0)) sem = 0.0;
+            const double kw = m > 0 ? (double)it.cnt / (double)m : 0.0;
+            const double w = 1.0 - boost;
+            volatile double p1 = sem * w;
+            volatile double p2 = kw * boost;
+            it.comb = p1 + p2;
+            if (have == n && !full_better(&it, &best[n - 1])) continue;
+            int j = have < n ? have++ : n - 1;
+            while (j > 0 && full_better(&it, &best[j - 1])) {
+                best[j] = best[j - 1];
+                --j;
+            }
+            best[j] = it;
+        }
+        for (int i = 0; i < n; ++i) {
+            const size_t o = (size_t)b * n + i;
+            out_rows[o] = i < have ? (int64_t)(best[i].key & 0xFFFFFFFFu) : -1;
+            out_combined[o] = i < have ? best[i].comb : -1.0;
+            out_counts[o] = i < have ? best[i].cnt : 0;
+            out_dist[o] = i < have ? orderable_f32((uint32_t)(best[i].key >> 32)) : INFINITY;
+        }
+        free(best);
+    }
+}

@@ -120,3 +120,22 @@ def fuse_sort(dist, counts, n_terms, n, boost=0.3, nvalid=None):
     kw = np.zeros((B, c), np.float64)
     lib().hrs_oracle_fuse_sort(_p(dist), _p(counts), _p(n_terms), _p(nvalid), C.c_int(B), C.c_int(c), C.c_double(boost), C.c_int(n), _p(comb), _p(perm), _p(sem), _p(kw))
     return comb, perm, sem, kw
+
+
+def hybrid_full(Q, Cm, doc_offs, term_ids, q_term_offs, q_terms, n, boost=0.3, space="l2"):
+    """Full-corpus fusion by brute force (an extension of the reference's re-rank; parity unpinned)
+    -> rows int64 [B,n], combined fp64 [B,n], counts int32 [B,n], dist fp32 [B,n]."""
+    Q = np.ascontiguousarray(Q, np.float32)
+    Cm = np.ascontiguousarray(Cm, np.float32)
+    doc_offs = np.ascontiguousarray(doc_offs, np.int64)
+    term_ids = np.ascontiguousarray(term_ids, np.int32)
+    q_term_offs = np.ascontiguousarray(q_term_offs, np.int32)
+    q_terms = np.ascontiguousarray(q_terms, np.int32)
+    B, D = Q.shape
+    rows = np.empty((B, n), np.int64)
+    comb = np.empty((B, n), np.float64)
+    counts = np.empty((B, n), np.int32)
+    dist = np.empty((B, n), np.float32)
+    lib().hrs_oracle_hybrid_full(_p(Q), _p(Cm), C.c_int64(Cm.shape[0]), C.c_int(D), C.c_int(B), C.c_int(SPACES[space]), _p(doc_offs), _p(term_ids),
+                                 _p(q_term_offs), _p(q_terms), C.c_int(n), C.c_double(boost), _p(rows), _p(comb), _p(counts), _p(dist))
+    return rows, comb, counts, dist

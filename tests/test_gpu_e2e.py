@@ -210,3 +210,26 @@ def test_incremental_collection_and_device_side_where(tmp_path):
     assert col._corpus.n == total and col._dev.shape[0] >= total
     again = Client(str(tmp_path)).get_or_create_collection("inc-where")
     assert again.count() == total and again.query(query_embeddings=q, n_results=4)["ids"] == col.query(query_embeddings=q, n_results=4)["ids"]
+
+
+def test_full_corpus_hybrid_flag_on_the_text_path(helper, monkeypatch):
+    """HRS_HYBRID_FULL=1 / full_corpus=True (an extension; off by default): the reference's fused score with its
+    substring keyword test, but the n best over the WHOLE collection -- equal to the reference's own fusion
+    arithmetic applied to every document listed nearest first."""
+    if helper.get_collection("cfg1").count() == 0:
+        helper.index_directory(CORPUS_DIR, ["*.md"], "cfg1")
+    col = helper.get_collection("cfg1")
+    differs = 0
+    for q in QUERIES + ["powershell", "docker compose volumes backup"]:
+        qe = helper.embed([q]).cpu().numpy()
+        wd, wr = so.topk(qe, col._emb, col.count(), "l2")  # every document, nearest first
+        want = T.fuse([col.documents[r] for r in wr[0]], [col.metadatas[r] for r in wr[0]], [col.ids[r] for r in wr[0]], [float(x) for x in wd[0]], q, 5)
+        got = helper.hybrid_query(q, 5, "cfg1", full_corpus=True)
+        assert got == want, q
+        plain = helper.hybrid_query(q, 5, "cfg1")
+        differs += [g["id"] for g in got] != [p["id"] for p in plain]
+        monkeypatch.setenv("HRS_HYBRID_FULL", "1")
+        assert helper.hybrid_query(q, 5, "cfg1") == got
+        monkeypatch.delenv("HRS_HYBRID_FULL")
+        assert helper.hybrid_query(q, 5, "cfg1") == plain  # the default stays the reference's re-rank
+    assert differs >= 1  # somewhere a keyword match lies outside the 2n nearest rows

@@ -609,3 +609,61 @@ def test_topk_resumed_behind_a_key_concatenates_to_the_exact_order(eng):
     assert (r2[:, :22] >= 0).all() and (r2[:, 22:] == -1).all() and (r3 == -1).all()
     small.close()
     corpus.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine"])
+def test_full_corpus_hybrid_equals_brute_force(eng, space):
+    """The full-corpus hybrid mode (an extension behind its own entry points; the reference's re-rank of the 2n
+    nearest stays the default): match counts of EVERY row from inverted postings, the best n of every match-count
+    class, fusion -- against the oracle's brute force over all rows (own semantics, parity unpinned)."""
+    from hybrid_rag_system_amd.engine import InvertedPostings
+
+    rng = np.random.default_rng(61)
+    n, d, B, V, n_keep = 30_011, 96, 23, 300, 10
+    C = _unit(rng, n, d)
+    C[200:260] = C[7]  # ties inside and across match-count classes
+    Q = _unit(rng, B, d)
+    for j in range(8):
+        Q[j] = C[j * 1000 + 7] + 0.2 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+        Q[j] /= np.linalg.norm(Q[j])
+    # ragged term lists (0..12 distinct terms per row, Zipf-like popularity so that some terms are in most rows)
+    p = 1.0 / np.arange(1, V + 1)
+    p /= p.sum()
+    lens = rng.integers(0, 13, n)
+    lists = [np.sort(rng.choice(V, int(l), replace=False, p=p)).astype(np.int32) for l in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    terms = np.concatenate(lists + [np.empty(0, np.int32)]).astype(np.int32)
+    m = rng.integers(0, 8, B)  # queries without keywords too
+    m[0] = 7
+    qoffs = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms = np.concatenate([rng.choice(V, int(mm), replace=False, p=p) for mm in m] + [np.empty(0, np.int64)]).astype(np.int32)
+    qterms[0] = 0  # the most popular term
+    if m[0] > 1:
+        qterms[1] = V - 1  # and a rare one
+    want_rows, want_comb, want_cnt, want_dist = so.hybrid_full(Q, C, offs, terms, qoffs, qterms, n_keep, 0.3, space)
+
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    inv = InvertedPostings.from_forward(eng, torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda(), V)
+    # the match counts of every row equal a host count over the forward lists
+    counts = eng.match_counts(inv, torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), B)
+    torch.cuda.synchronize()
+    hc = np.zeros((B, n), np.uint8)
+    for b in range(B):
+        qs = set(qterms[qoffs[b] : qoffs[b + 1]].tolist())
+        hc[b] = [len(qs.intersection(l.tolist())) for l in lists]
+    assert np.array_equal(counts.cpu().numpy()[:, :n], hc)
+    for chunk in (4 << 30, 5 * n):  # all queries at once, and in chunks of five
+        out = eng.hybrid_full_corpus(corpus, inv, torch.from_numpy(Q).cuda(), torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), n_keep, 0.3, space, chunk_bytes=chunk)
+        torch.cuda.synchronize()
+        assert np.array_equal(out["rows"].cpu().numpy(), want_rows)
+        assert np.array_equal(out["counts"].cpu().numpy(), want_cnt)
+        assert np.array_equal(out["dist"].cpu().numpy(), want_dist)
+        assert np.array_equal(out["combined"].cpu().numpy().view(np.uint64), want_comb.view(np.uint64))
+    # it differs from the reference's re-rank where a keyword match lies outside the 2n nearest rows
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
+    rr = eng.hybrid_topk(corpus, post, torch.from_numpy(Q).cuda(), torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), n_keep, space=space)
+    torch.cuda.synchronize()
+    assert (rr["combined"].cpu().numpy()[:, 0] <= want_comb[:, 0] + 1e-15).all() and (rr["combined"].cpu().numpy() < want_comb - 1e-9).any()
+    inv.close()
+    post.close()
+    corpus.close()
