@@ -225,3 +225,53 @@ class HybridPipeline:
                 if searcher.exchange_stream is not None:
                     torch.cuda.current_stream().wait_stream(searcher.exchange_stream)
         return last
+
+
+class TopKPipeline:
+    """Plain top-k scoring (collection.query without the keyword stage) with consecutive batches on alternating
+    streams / contexts, as HybridPipeline does for the hybrid step: batch i + 1's scan is enqueued before batch i's
+    tail, which then runs under it.  `submit` returns the (dist, rows, keys) of the previous batch, consumable on the
+    caller's stream; `drain` the last."""
+
+    def __init__(self, engines, corpus):
+        self.corpus = corpus
+        self.lanes = [(e, torch.cuda.Stream(device=e.device)) for e in engines]
+        for j, e in enumerate(engines):
+            if len(engines) > 1:
+                e.set_peer(engines[j - 1])
+        self.n = 0
+        self._open = None
+
+    def _finish_open(self):
+        if self._open is None:
+            return None
+        eng, stream = self._open
+        self._open = None
+        with torch.cuda.stream(stream):
+            out = eng.score_topk_finish(want_keys=True)
+            done = torch.cuda.Event()
+            done.record()
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        for t in out:
+            t.record_stream(cur)
+        return out
+
+    def submit(self, queries, k, space="l2", mask=None, mode="auto"):
+        eng, stream = self.lanes[self.n % len(self.lanes)]
+        self.n += 1
+        prev = self._finish_open() if len(self.lanes) == 1 else None
+        stream.wait_stream(torch.cuda.current_stream())
+        queries.record_stream(stream)
+        with torch.cuda.stream(stream):
+            eng.score_topk_begin(self.corpus, queries, k, space=space, mask=mask, mode=mode)
+        if len(self.lanes) > 1:
+            prev = self._finish_open()
+        self._open = (eng, stream)
+        return prev
+
+    def drain(self):
+        last = self._finish_open()
+        for _, stream in self.lanes:
+            torch.cuda.current_stream().wait_stream(stream)
+        return last
