@@ -39,6 +39,23 @@ def allgather_candidates(keys, counts, group=None):
     return out[..., 0].contiguous(), out[..., 1].to(torch.int32).contiguous()
 
 
+def exchange_classes(engine, group=None):
+    """-> the `exchange` step of Engine.hybrid_full_corpus on a row-sharded corpus: one all-gather of every shard's
+    per-class candidates (keys int64 [B, levels, n], local rows already carry the shard's row offset), then the
+    per-class merge on every rank."""
+
+    def exchange(keys):
+        world = dist.get_world_size(group)
+        staged = keys.is_cuda and dist.get_backend(group) == "gloo"  # see allgather_candidates
+        src = (keys.cpu() if staged else keys).contiguous()
+        flat = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(flat, src, group=group)
+        gathered = flat.view((world,) + tuple(src.shape))
+        return engine.merge_classes(gathered.to(keys.device) if staged else gathered)
+
+    return exchange
+
+
 def embed_data_parallel(embed_fn, texts, group=None):
     """Indexing is data-parallel: rank r embeds the contiguous slice of `texts` that shard_bounds gives it
     (the rows it will own) with `embed_fn(list[str]) -> fp32 [n, D]`, and nothing is exchanged.

@@ -330,11 +330,38 @@ class Engine:
         )
         return keys
 
-    def hybrid_full_corpus(self, corpus, inverted, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", max_terms=None, chunk_bytes=4 << 30):
+    def full_corpus_local(self, corpus, inverted, queries, q_terms, q_term_offs, n, levels, space="l2"):
+        """First half of the full-corpus hybrid mode on one shard: match counts of every local row, then the n nearest
+        rows of every match-count class -> keys int64 (uint64 bits) [B, levels, n]."""
+        counts = self.match_counts(inverted, q_terms, q_term_offs, queries.shape[0])
+        return self.score_topk_levels(corpus, queries, n, levels, counts, space)
+
+    def full_corpus_finish(self, keys, q_term_offs, n, boost=0.3):
+        """Second half: keys [B, levels, n] (of one shard, or merged per class over all shards) -> the n best rows under
+        the fused score.  The class index IS the keyword match count."""
+        B, levels, k = keys.shape
+        lv = torch.arange(levels, dtype=torch.int32, device=self.device).view(1, levels, 1).expand(B, levels, k).contiguous()
+        skeys, scnt = self.merge_topk(keys.reshape(1, B, levels * k), lv.view(1, B, levels * k))  # all candidates, nearest first
+        dist, rows = self.unpack_keys(skeys)
+        combined, perm = self.fuse_sort(dist, scnt, q_term_offs, n, boost)
+        idx = perm.clamp(min=0).to(torch.int64)
+        miss = perm < 0
+        return {"rows": torch.gather(rows, 1, idx).masked_fill(miss, -1), "dist": torch.gather(dist, 1, idx).masked_fill(miss, float("inf")),
+                "counts": torch.gather(scnt, 1, idx).masked_fill(miss, 0), "combined": combined}
+
+    def merge_classes(self, gathered):
+        """gathered int64 [G, B, levels, n]: every shard's nearest n of every class -> [B, levels, n] over all shards."""
+        G, B, levels, k = gathered.shape
+        return self.merge_topk(gathered.reshape(G, B * levels, k).contiguous()).view(B, levels, k)
+
+    def hybrid_full_corpus(self, corpus, inverted, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", max_terms=None, chunk_bytes=4 << 30,
+                           exchange=None):
         """Full-corpus hybrid mode (an extension; the reference's behaviour is hybrid_topk): the n best rows of the
-        WHOLE shard under the fused score of scripts/chromadb_helper.py:302-325 (keyword fraction over term ids),
+        WHOLE corpus under the fused score of scripts/chromadb_helper.py:302-325 (keyword fraction over term ids),
         ties by (distance, row).  Exact: the best n of every match-count class 0..m by distance contain the best n
-        overall.  Queries are processed in chunks whose [chunk, rows] count matrix fits `chunk_bytes`.
+        overall.  Queries are processed in chunks whose [chunk, rows] count matrix fits `chunk_bytes`.  On a
+        row-sharded corpus `exchange` (keys [B, levels, n] of this shard -> the same over all shards, e.g.
+        dist.exchange_classes) sits between the halves; every rank then holds the same result.
         -> dict(rows int64 [B,n], dist fp32 [B,n], counts int32 [B,n], combined fp64 [B,n])."""
         B = queries.shape[0]
         if max_terms is None:
@@ -350,18 +377,12 @@ class Engine:
             qt = q_terms[int(q_term_offs[b0].item()) :]
             if qt.numel() == 0:
                 qt = torch.zeros(1, dtype=torch.int32, device=self.device)
-            counts = self.match_counts(inverted, qt, qo, b1 - b0)
-            keys = self.score_topk_levels(corpus, queries[b0:b1].contiguous(), n, levels, counts, space)
-            lv = torch.arange(levels, dtype=torch.int32, device=self.device).view(1, levels, 1).expand(b1 - b0, levels, n).contiguous()
-            skeys, scnt = self.merge_topk(keys.view(1, b1 - b0, levels * n), lv.view(1, b1 - b0, levels * n))  # all candidates, nearest first
-            dist, rows = self.unpack_keys(skeys)
-            combined, perm = self.fuse_sort(dist, scnt, qo, n, boost)
-            idx = perm.clamp(min=0).to(torch.int64)
-            miss = perm < 0
-            out["rows"].append(torch.gather(rows, 1, idx).masked_fill(miss, -1))
-            out["dist"].append(torch.gather(dist, 1, idx).masked_fill(miss, float("inf")))
-            out["counts"].append(torch.gather(scnt, 1, idx).masked_fill(miss, 0))
-            out["combined"].append(combined)
+            keys = self.full_corpus_local(corpus, inverted, queries[b0:b1].contiguous(), qt, qo, n, levels, space)
+            if exchange is not None:
+                keys = exchange(keys)
+            part = self.full_corpus_finish(keys, qo, n, boost)
+            for k in out:
+                out[k].append(part[k])
         return {k: torch.cat(v) for k, v in out.items()}
 
     def merge_topk(self, keys, vals=None):

@@ -168,3 +168,33 @@ def test_two_rank_pipelined_hybrid_step_equals_unsharded():
             assert np.array_equal(o["cand_rows"], wr) and np.array_equal(o["cand_dist"], wd)
             assert np.array_equal(o["cand_counts"], wcnt) and np.array_equal(o["perm"], wp)
             assert np.array_equal(o["combined"].view(np.uint64), wc.view(np.uint64))
+
+
+def _classes_worker(rank, world, port, ret):
+    from hybrid_rag_system_amd.dist import exchange_classes
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Merger:  # Engine.merge_classes by the oracle
+        def merge_classes(self, gathered):
+            G, B, L, k = gathered.shape
+            return torch.from_numpy(so.merge(gathered.numpy().view(np.uint64).reshape(G, B * L, k)).view(np.int64).reshape(B, L, k))
+
+    rng = np.random.default_rng(100 + rank)
+    keys = np.sort(rng.integers(0, 2**62, (3, 4, 5)).astype(np.uint64), axis=2)  # this shard's [B, levels, n]
+    out = exchange_classes(_Merger())(torch.from_numpy(keys.view(np.int64)))
+    ret[rank] = (keys, out.numpy().view(np.uint64))
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_of_per_class_candidates():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_classes_worker, args=(world, port, ret), nprocs=world, join=True)
+    both = np.stack([ret[0][0], ret[1][0]])  # [G, B, L, n]
+    want = np.sort(both.transpose(1, 2, 0, 3).reshape(3, 4, 10), axis=2)[:, :, :5]
+    assert np.array_equal(ret[0][1], want) and np.array_equal(ret[1][1], want)

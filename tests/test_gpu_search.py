@@ -659,6 +659,27 @@ def test_full_corpus_hybrid_equals_brute_force(eng, space):
         assert np.array_equal(out["counts"].cpu().numpy(), want_cnt)
         assert np.array_equal(out["dist"].cpu().numpy(), want_dist)
         assert np.array_equal(out["combined"].cpu().numpy().view(np.uint64), want_comb.view(np.uint64))
+    # row-sharded: every shard's nearest n of every class, merged per class (what dist.exchange_classes does after its
+    # all-gather), then the same second half -- equal to the unsharded result
+    qd, td, od = torch.from_numpy(Q).cuda(), torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda()
+    levels = int(m.max()) + 1
+    for G in (2, 3):
+        bounds = [n * g // G for g in range(G + 1)]
+        parts, keep = [], []
+        for g in range(G):
+            lo, hi = bounds[g], bounds[g + 1]
+            cp = eng.corpus(torch.from_numpy(C[lo:hi]).cuda(), row_offset=lo)
+            so_, st_ = torch.from_numpy(offs[lo : hi + 1] - offs[lo]).cuda(), torch.from_numpy(terms[offs[lo] : offs[hi]]).cuda()
+            iv = InvertedPostings.from_forward(eng, so_, st_ if st_.numel() else torch.zeros(1, dtype=torch.int32, device="cuda"), V)
+            keep += [cp, iv]
+            parts.append(eng.full_corpus_local(cp, iv, qd, td, od, n_keep, levels, space))
+        merged = eng.merge_classes(torch.stack(parts))
+        got = eng.full_corpus_finish(merged, od, n_keep, 0.3)
+        torch.cuda.synchronize()
+        assert np.array_equal(got["rows"].cpu().numpy(), want_rows), G
+        assert np.array_equal(got["combined"].cpu().numpy().view(np.uint64), want_comb.view(np.uint64)), G
+        for h in keep:
+            h.close()
     # it differs from the reference's re-rank where a keyword match lies outside the 2n nearest rows
     post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
     rr = eng.hybrid_topk(corpus, post, torch.from_numpy(Q).cuda(), torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), n_keep, space=space)
