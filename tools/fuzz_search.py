@@ -43,8 +43,12 @@ def run(eng, seed, cases, verbose=True, large=False):
       want = so.topk_keys(Q, C, k, space, mask=mask)
       dC, dQ = torch.from_numpy(C).cuda(), torch.from_numpy(Q).cuda()
       dm = torch.from_numpy(mask).cuda() if use_mask else None
+      grow = rng.random() < 0.3  # the corpus arrives in pieces (hrs_corpus_append) instead of in one registration
+      cuts = sorted(set(int(x) for x in rng.integers(1, n, int(rng.integers(1, 4))))) + [n] if grow else [n]
       for shadow in ("i8", "bf16"):
-          c = eng.corpus(dC, shadow=shadow)
+          c = eng.corpus(dC, shadow=shadow, n=cuts[0])
+          for cut in cuts[1:]:
+              c.append(dC, cut)
           for mode in ("mfma", "exact", "auto"):
               if mode == "exact" and shadow == "bf16": continue
               _, _, keys = eng.score_topk(c, dQ, k, space=space, mask=dm, mode=mode, want_keys=True)
@@ -53,7 +57,7 @@ def run(eng, seed, cases, verbose=True, large=False):
                   bad += 1
                   print(f"MISMATCH it={it} n={n} d={d} b={b} k={k} {space} kind={kind} mask={use_mask} {shadow} {mode} {eng.score_stats()}", flush=True)
           c.close()
-      if verbose: print(f"case {it}: n={n} d={d} b={b} k={k} {space} kind={kind} mask={use_mask} ok", flush=True)
+      if verbose: print(f"case {it}: n={n} d={d} b={b} k={k} {space} kind={kind} mask={use_mask} grow={cuts if grow else 0} ok", flush=True)
   return bad
 
 
