@@ -40,3 +40,52 @@ def test_asm_mfma_kernels_do_not_spill(src, needle, tmp_path):
     for name, k in ks.items():
         assert int(k["vgpr_spill_count"]) == 0, (name, k)
         assert int(k["private_segment_fixed_size"]) == 0, (name, k)
+
+
+def _kernel_bodies(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    if not out.exists():
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
+                               "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
+    bodies, name, cur = {}, None, []
+    for line in out.read_text().splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name, cur = m.group(1), []
+        elif line.startswith(".Lfunc_end") and name:
+            bodies[name] = cur
+            name = None
+        elif name is not None:
+            t = line.strip()
+            if t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
+                cur.append(t)
+    return bodies
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
+@pytest.mark.parametrize("src,needle", [("hrs_encoder.hip", "k_gemm_down"), ("hrs_mfma.hip", "k_mfma_scan_wide")])
+def test_asm_mfma_hazard_padding(src, needle, tmp_path):
+    """The hand-issued MFMAs of these kernels carry their own wait states: every one is directly preceded by an s_nop
+    (a vector write of an operand may sit right in front of the asm statement), and no instruction other than an MFMA
+    touches an accumulator register until at least 18 wait states after the last MFMA (the result of an 8-pass MFMA is
+    not interlocked for other readers)."""
+    found = 0
+    for name, body in _kernel_bodies(src, tmp_path).items():
+        if needle not in name:
+            continue
+        last_mfma, since = None, 0
+        for idx, ins in enumerate(body):
+            op = ins.split()[0]
+            if op.startswith("v_mfma"):
+                found += 1
+                assert body[idx - 1].startswith("s_nop"), (name, idx, body[idx - 1])
+                last_mfma, since = idx, 0
+                continue
+            if last_mfma is not None:
+                touches_acc = re.search(r"\ba\[?\d", ins) is not None
+                if touches_acc:
+                    assert since >= 18, (name, idx, ins, since)
+                    last_mfma = None  # checked up to the first reader
+                    continue
+                since += (int(ins.split()[1]) + 1) if op == "s_nop" else 1
+    assert found >= 64
