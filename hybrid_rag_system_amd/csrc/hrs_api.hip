@@ -200,9 +200,10 @@ extern "C" int hrs_score_topk_after(hrs_ctx* ctx, hrs_corpus* c, const float* Q_
         if (rc0) return rc0;
         keys = (uint64_t*)ctx->ws_keys.ptr;
     }
-    rc = hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, (hipStream_t)stream, after_keys_dev);
-    if (rc == HRS_OK && (dist_dev || rows_dev)) rc = hrs_unpack_keys(ctx, keys, (int64_t)B * k, dist_dev, rows_dev, stream);
-    return rc;
+    hrs_unpacked un;
+    un.dist = dist_dev;
+    un.rows = rows_dev;
+    return hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, (hipStream_t)stream, after_keys_dev, 0, -1, 0, un);
 }
 
 extern "C" int hrs_score_topk_levels(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
@@ -314,11 +315,12 @@ extern "C" int hrs_score_topk(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, i
         if (rc0) return rc0;
         keys = (uint64_t*)ctx->ws_keys.ptr;
     }
-    rc = pick_mfma(c, B, k, mode) ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st)
-                                  : hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, st);
-    if (rc == HRS_OK && (dist_dev || rows_dev))
-        rc = hrs_unpack_keys(ctx, keys, (int64_t)B * k, dist_dev, rows_dev, stream);
-    return rc;
+    // the kernels that write a query's final keys unpack them too: no launch of its own for that
+    hrs_unpacked un;
+    un.dist = dist_dev;
+    un.rows = rows_dev;
+    return pick_mfma(c, B, k, mode) ? hrs_launch_mfma(ctx, c, Q_dev, B, k, space, row_mask_dev, keys, st, HRS_PHASE_ALL, un)
+                                    : hrs_launch_exact(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys, st, nullptr, 0, -1, 0, un);
 }
 
 extern "C" int hrs_score_topk_begin(hrs_ctx* ctx, hrs_corpus* c, const float* Q_dev, int B, int k, int space,
@@ -358,10 +360,10 @@ extern "C" int hrs_score_topk_finish(hrs_ctx* ctx, uint64_t* keys_dev, float* di
         if (rc0) return rc0;
         keys = (uint64_t*)ctx->ws_keys.ptr;
     }
-    int rc = hrs_launch_mfma(ctx, p.c, p.Q, p.B, p.k, p.space, p.mask, keys, (hipStream_t)stream, HRS_PHASE_TAIL);
-    if (rc == HRS_OK && (dist_dev || rows_dev))
-        rc = hrs_unpack_keys(ctx, keys, (int64_t)p.B * p.k, dist_dev, rows_dev, stream);
-    return rc;
+    hrs_unpacked un;
+    un.dist = dist_dev;
+    un.rows = rows_dev;
+    return hrs_launch_mfma(ctx, p.c, p.Q, p.B, p.k, p.space, p.mask, keys, (hipStream_t)stream, HRS_PHASE_TAIL, un);
 }
 
 extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
@@ -372,6 +374,9 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     out[0] = h[0];
     out[1] = h[1];
     out[2] = h[2];
+#ifdef HRS_SEL_PROF
+    fprintf(stderr, "select: init %lld resc %lld total %lld (x10 ns, summed over queries) rounds %lld maxcand %lld\n", (long long)h[4], (long long)h[5], (long long)h[6], (long long)h[7], (long long)h[1]);
+#endif
     return HRS_OK;
 }
 

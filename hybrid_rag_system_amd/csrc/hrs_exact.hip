@@ -278,6 +278,8 @@ struct MergeArgs {
     const int32_t* qlist;  // final level only: scatter to out[qlist[q]]
     int final_level;
     int64_t out_stride;    // final level: keys of query q go to out + q * out_stride (k when the lists are dense)
+    float* dist_out;       // final level, nullable: the keys unpacked, [nq][k] ...
+    int64_t* rows_out;     // ... (only with out_stride == k)
 };
 
 __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
@@ -298,7 +300,44 @@ __global__ __launch_bounds__(256) void k_merge_lists(MergeArgs a) {
         dst = a.out + (size_t)(a.qlist ? a.qlist[q] : q) * a.out_stride;
     else
         dst = a.out + ((size_t)q * ngroups + g) * a.k;
-    for (int i = threadIdx.x; i < a.k; i += 256) dst[i] = i < n2 ? s[i] : HRS_PAD_KEY;
+    for (int i = threadIdx.x; i < a.k; i += 256) {
+        const uint64_t key = i < n2 ? s[i] : HRS_PAD_KEY;
+        dst[i] = key;
+        if (a.final_level) hrs_store_unpacked(key, (size_t)(a.qlist ? a.qlist[q] : q) * a.k + i, a.dist_out, a.rows_out);
+    }
+}
+
+// Both levels in one launch, one workgroup per query: the groups of `per` lists one after the other, then their
+// winners.  For the queue of queries that the matrix-core path could not prove (device-side count, nearly always
+// zero): the launch saved matters on every call, the serial groups only for a query that is actually queued.
+__global__ __launch_bounds__(256) void k_merge_lists_serial(MergeArgs a) {
+    __shared__ uint64_t s[2048], top[2048];
+    const int nq = a.nq_dev ? min(*a.nq_dev, a.nq) : a.nq;
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int ngroups = (a.nlists + a.per - 1) / a.per;  // at most 2048 / k
+    for (int g = 0; g < ngroups; ++g) {
+        const int l0 = g * a.per, l1 = min(a.nlists, l0 + a.per);
+        const int n = (l1 - l0) * a.k;
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        const uint64_t* src = a.in + ((size_t)q * a.nlists + l0) * a.k;
+        for (int i = threadIdx.x; i < n2; i += 256) s[i] = i < n ? src[i] : HRS_PAD_KEY;
+        bitonic_sort_u64(s, n2, threadIdx.x, 256);
+        for (int i = threadIdx.x; i < a.k; i += 256) top[g * a.k + i] = i < n2 ? s[i] : HRS_PAD_KEY;
+        __syncthreads();
+    }
+    const int n = ngroups * a.k;
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 256) s[i] = i < n ? top[i] : HRS_PAD_KEY;
+    bitonic_sort_u64(s, n2, threadIdx.x, 256);
+    const size_t qo = (size_t)(a.qlist ? a.qlist[q] : q);
+    for (int i = threadIdx.x; i < a.k; i += 256) {
+        const uint64_t key = i < n2 ? s[i] : HRS_PAD_KEY;
+        a.out[qo * a.out_stride + i] = key;
+        hrs_store_unpacked(key, qo * a.k + i, a.dist_out, a.rows_out);
+    }
 }
 
 template <int SPACE, int BQ>
@@ -330,7 +369,7 @@ static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipS
 static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, uint64_t* p0, int grid, bool timed,
                      hipStream_t st, const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1,
-                     int64_t out_stride = 0) {
+                     int64_t out_stride = 0, hrs_unpacked un = hrs_unpacked()) {
     const int64_t tiles = (c->N + ER - 1) / ER;
     const int per = 16;
     const int g1 = (grid + per - 1) / per;
@@ -379,7 +418,15 @@ static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     m.per = per;
     m.qlist = qlist;
     m.out_stride = out_stride ? out_stride : k;
-    if (g1 > 1) {
+    m.dist_out = m.out_stride == k ? un.dist : nullptr;
+    m.rows_out = m.out_stride == k ? un.rows : nullptr;
+    if (g1 > 1 && nq_dev && (int64_t)g1 * k <= 2048) {
+        m.in = p0;
+        m.out = keys_out;
+        m.nlists = grid;
+        m.final_level = 1;
+        hipLaunchKernelGGL(k_merge_lists_serial, dim3(B), dim3(256), 0, st, m);
+    } else if (g1 > 1) {
         m.in = p0;
         m.out = p1;
         m.nlists = grid;
@@ -411,13 +458,13 @@ static size_t exact_scratch_words(int B, int grid, int k) {
 
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st, const uint64_t* after,
-                     int64_t mask_qstride, int mask_eq, int64_t out_stride) {
+                     int64_t mask_qstride, int mask_eq, int64_t out_stride, hrs_unpacked un) {
     if (B <= 0) return HRS_OK;
     const int grid = exact_grid(ctx, c);
     int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, exact_scratch_words(B, grid, k) * sizeof(uint64_t));
     if (rc) return rc;
     return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st, after,
-                     mask_qstride, mask_eq, out_stride);
+                     mask_qstride, mask_eq, out_stride, un);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------------
@@ -459,7 +506,8 @@ extern "C" int hrs_score_topk_static(hrs_ctx* ctx, hrs_corpus* c, const float* Q
         return HRS_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = exact_run(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys_dev, scratch, grid, false, st);
-    if (rc == HRS_OK && (dist_dev || rows_dev)) rc = hrs_unpack_keys(ctx, keys_dev, (int64_t)B * k, dist_dev, rows_dev, stream);
-    return rc;
+    hrs_unpacked un;
+    un.dist = dist_dev;
+    un.rows = rows_dev;
+    return exact_run(ctx, c, Q_dev, B, k, space, row_mask_dev, nullptr, nullptr, keys_dev, scratch, grid, false, st, nullptr, 0, -1, 0, un);
 }

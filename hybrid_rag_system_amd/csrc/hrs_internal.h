@@ -131,6 +131,13 @@ __device__ __forceinline__ uint64_t pack_key(float d32, uint32_t row) {
     return ((uint64_t)f32_orderable(d32) << 32) | row;
 }
 
+// One final key, unpacked into the caller's distance / row arrays (either may be null).
+__device__ __forceinline__ void hrs_store_unpacked(uint64_t key, size_t at, float* dist, int64_t* rows) {
+    const bool pad = key == HRS_PAD_KEY;
+    if (dist) dist[at] = pad ? __builtin_inff() : orderable_f32((uint32_t)(key >> 32));
+    if (rows) rows[at] = pad ? -1 : (int64_t)(key & 0xFFFFFFFFull);
+}
+
 // Bitonic sort of n (power of two) uint64 keys in LDS, ascending; all threads of the block call it.
 // Every thread owns compare-exchange PAIRS (pair p of a pass with stride j joins i = p with a zero bit
 // inserted at j, and i + j), four at a time so that their LDS reads are in flight together.
@@ -164,6 +171,78 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t* s, int n, int tid, in
     __syncthreads();
 }
 
+// The same order for 256 * E keys (E = 1, 2, 4 or 8) and a workgroup of 256 threads, with the keys in registers:
+// thread t holds keys t*E .. t*E+E-1.  Compare-exchanges at a distance below E are local, those within a wave
+// (distance below 64 E) go through lane shuffles, and only the few across waves go through LDS -- three stages
+// with a barrier instead of one barrier per stage (36 to 66 of them).  s must be complete (a barrier behind the
+// last write) on entry; it is complete and sorted on return.
+template <int E>
+__device__ __forceinline__ void bitonic_sort_u64_regs(uint64_t* s, int tid) {
+    constexpr int n = 256 * E;
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = s[tid * E + e];
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j >= E; j >>= 1) {  // partners in other threads
+            if (j >= 64 * E) {
+                __syncthreads();  // every thread has read what it wanted from the previous contents
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[tid * E + e] = v[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const uint64_t o = s[i ^ j];
+                    const bool take_min = ((i & k) == 0) == ((i & j) == 0);
+                    v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+                }
+            } else {
+                const int d = j / E;  // lane distance
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v[e], d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v[e] >> 32), d);
+                    const uint64_t o = ((uint64_t)hi << 32) | lo;
+                    const bool take_min = ((i & k) == 0) == ((i & j) == 0);
+                    v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = E / 2; jj > 0; jj >>= 1) {  // partners in this thread
+            if (jj < k) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & jj) == 0) {
+                        const bool up = (((tid * E + e) & k) == 0);
+                        const uint64_t a = v[e], b = v[e | jj];
+                        if ((a > b) == up) {
+                            v[e] = b;
+                            v[e | jj] = a;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[tid * E + e] = v[e];
+    __syncthreads();
+}
+// n: 256, 512, 1024 or 2048 keys; 256 threads
+__device__ __forceinline__ void bitonic_sort_u64_256t(uint64_t* s, int n, int tid) {
+    __syncthreads();
+    if (n == 256)
+        bitonic_sort_u64_regs<1>(s, tid);
+    else if (n == 512)
+        bitonic_sort_u64_regs<2>(s, tid);
+    else if (n == 1024)
+        bitonic_sort_u64_regs<4>(s, tid);
+    else
+        bitonic_sort_u64_regs<8>(s, tid);
+}
+
 // LDS-DMA: 16 bytes per lane from (scalar base + per-lane byte offset) to LDS at lds_addr + lane*16.
 // Written as inline asm so that the compiler neither counts it nor drains it with a vmcnt(0) before
 // unrelated LDS reads; the caller owns the s_waitcnt vmcnt(N) that retires it.  M0 (the DMA's LDS
@@ -188,14 +267,21 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 }
 
 // Launchers implemented in the kernel files.
+// Where the kernel that writes a query's final keys also writes them unpacked (either may be null): [B][k]
+// distances and rows, +inf and -1 where fewer than k rows exist.
+struct hrs_unpacked {
+    float* dist = nullptr;
+    int64_t* rows = nullptr;
+};
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st,
-                     const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1, int64_t out_stride = 0);
+                     const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1, int64_t out_stride = 0,
+                     hrs_unpacked un = hrs_unpacked());
 // phase: HRS_PHASE_ALL the whole call; HRS_PHASE_SCAN up to and including the main pass (B <= 1024);
 // HRS_PHASE_TAIL the rest of a call whose scan phase ran with the same arguments
 enum { HRS_PHASE_ALL = 0, HRS_PHASE_SCAN = 1, HRS_PHASE_TAIL = 2 };
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                    uint64_t* keys_out, hipStream_t st, int phase = HRS_PHASE_ALL);
+                    uint64_t* keys_out, hipStream_t st, int phase = HRS_PHASE_ALL, hrs_unpacked un = hrs_unpacked());
 int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st);
 int hrs_append_shadow(hrs_ctx* ctx, hrs_corpus* c, const float* C, int64_t N_new, hipStream_t st);
 void hrs_free_shadow(hrs_corpus* c);

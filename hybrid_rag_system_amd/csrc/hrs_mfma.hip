@@ -26,6 +26,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // The scan runs on one of two shadows of the corpus.  bf16: v_mfma_f32_32x32x16_bf16, 16 depth
 // elements per k-step.  int8: v_mfma_i32_32x32x32_i8, 32 depth elements per k-step, twice the rate and
@@ -88,10 +89,38 @@ struct MfmaArgs {
     int* hist;             // ladder pass: [Bpad][16] sampled scores above tau, by sixteenth of that range
     const uint8_t* mask;   // nullable, [N]: rows with 0 are never recorded (the `where` filter)
     float* maxima;         // [Bpad][HRS_MAX_STREAMS]
-    const float* tau;      // [Bpad]
+    const float* tau;      // [Bpad] the first threshold (from the sampled maxima)
+    float* tau_out;        // [Bpad] MODE 0: the threshold the pass filtered by (raised where the ladder says so)
+    int raise_ss;          // MODE 0: sampling stride of the ladder pass
+    int raise_limit;       // MODE 0: estimated rows above the threshold that a list may hold
     int* cnt;              // [Bpad]
     uint64_t* cand;        // [Bpad][HRS_CAND_CAP_BIG]
 };
+
+// Rows of a topically ordered corpus do not score independently: whole runs of neighbours exceed the first
+// threshold together and the candidate lists would overflow.  The ladder pass has counted the sampled scores above
+// it in sixteen steps up to the largest sampled score; the threshold of the main pass is the first one moved up to
+// the lowest step above which the estimated number of rows (sampled count x sampling stride) fits a list.  It
+// never moves down.  Every workgroup of the main pass evaluates this for its own queries (the inputs are final
+// before the pass starts), which saves a launch between the ladder pass and the main pass.
+__device__ __forceinline__ float raised_tau(const MfmaArgs& a, int q) {
+    float t = a.tau[q];
+    const float li = a.lad_inv[q];
+    // all sixteen counts in one go (loads that depend on a loop's exit test would come one memory latency apiece)
+    const int4* hp = (const int4*)(a.hist + (size_t)q * 16);
+    const int4 h3 = hp[3], h2 = hp[2], h1 = hp[1], h0 = hp[0];
+    const int hv[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+    long long above = 0;
+    int step = 0;  // rows from step b upward are too many: start one step higher
+#pragma unroll
+    for (int b = 15; b >= 0; --b) {
+        above += hv[b];
+        if (step == 0 && above * a.raise_ss > a.raise_limit) step = b + 1;
+    }
+    if (step > 15) step = 15;
+    if (li > 0.f && step > 0) t += (float)step / li;
+    return t;
+}
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16;
@@ -158,7 +187,8 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     float mx[QT][WSUB];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        tau[qt] = MAXIMA ? 0.f : a.tau[q0 + qt * 32 + i];
+        tau[qt] = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + qt * 32 + i] : raised_tau(a, q0 + qt * 32 + i));
+        if (MODE == 0 && slice == 0 && sb0 == 0 && h == 0) a.tau_out[q0 + qt * 32 + i] = tau[qt];  // one writer per query
         kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
         linv[qt] = LADDER ? a.lad_inv[q0 + qt * 32 + i] : 0.f;
 #pragma unroll
@@ -172,6 +202,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]), "+v"(linv[qt]));
+    if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
@@ -469,7 +500,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
     bf16x8 qf[SPT * KSS];
 #pragma unroll
     for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + ((size_t)(q0 + i) * DP + s * 16 + h * 8) * 2);
-    const float tau = MAXIMA ? 0.f : a.tau[q0 + i];
+    const float tau = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + i] : raised_tau(a, q0 + i));
+    if (MODE == 0 && slice == 0 && h == 0) a.tau_out[q0 + i] = tau;  // one writer per query
     const float linv = LADDER ? a.lad_inv[q0 + i] : 0.f;
     float mx = -__builtin_inff();
 #pragma unroll
@@ -479,6 +511,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
         else
             asm volatile("" : "+v"(qf[s]));
     }
+    if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
@@ -996,29 +1029,6 @@ __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxi
     }
 }
 
-// Rows of a topically ordered corpus do not score independently: whole runs of neighbours exceed the
-// first tau together and the candidate lists would overflow.  The ladder pass has counted the sampled
-// scores above tau in sixteen steps up to the largest sampled score; tau moves up to the lowest step
-// above which the estimated number of rows (count x sampling stride) fits `limit`.  It never moves down.
-__global__ void k_raise_tau(float* __restrict__ tau, const float* __restrict__ lad_inv, const int* __restrict__ hist, int B,
-                            int ss, int limit) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= B) return;
-    const float li = lad_inv[q];
-    if (li <= 0.f) return;
-    long long above = 0;
-    int step = 0;
-    for (int b = 15; b >= 0; --b) {
-        above += hist[q * 16 + b];
-        if (above * ss > limit) {
-            step = b + 1;  // rows from step b upward are too many: start one step higher
-            break;
-        }
-    }
-    if (step > 15) step = 15;
-    if (step > 0) tau[q] += (float)step / li;
-}
-
 struct SelectArgs {
     const float* C;
     const float* Q;
@@ -1036,6 +1046,8 @@ struct SelectArgs {
     const float* qscale;       // int8 shadow only (else null): per-query scale; candidate scores are then
                                // upper bounds of score / scale
     uint64_t* keys_out;  // [B][k]
+    float* dist_out;     // nullable [B][k]: the keys' distances ...
+    int64_t* rows_out;   // nullable [B][k]: ... and rows (-1 and +inf where fewer than k rows exist)
     int32_t* qlist;      // queue of queries for the exact fallback
     int32_t* nflag;
     int32_t* qlist2;     // queue (chunk-local indices) of queries deferred to the large variant; [0] of nflag2 = count
@@ -1079,13 +1091,22 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         if (tid == 0) a.qlist2[atomicAdd(a.nflag2, 1)] = ql;
         return;
     }
+#ifdef HRS_SEL_PROF
+    long long pt0 = wall_clock64(), pt_resc = 0, pt_sort = 0, pt_rounds = 0;
+#endif
     int n2 = 256;
     while (n2 < c) n2 <<= 1;
     for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP_BIG + t] : HRS_PAD_KEY;
     for (int t = tid; t < RMAX; t += 256) ek[t] = HRS_PAD_KEY;
     const float* qr = a.Q + (size_t)q * a.D;
     for (int t = tid; t < a.D; t += 256) qs[t] = qr[t];
-    bitonic_sort_u64(s, n2, tid, 256);
+    auto sort_keys = [&](uint64_t* p, int n) __attribute__((always_inline)) {
+        if (n <= 2048)
+            bitonic_sort_u64_256t(p, n, tid);
+        else
+            bitonic_sort_u64(p, n, tid, 256);
+    };
+    sort_keys(s, n2);
 
     const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
     const double sq = a.qscale ? (double)a.qscale[ql] : 1.0;
@@ -1106,13 +1127,32 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     };
     double nq = 0.0;
     if (SPACE == HRS_SPACE_COSINE) {
-        // the oracle's |q|^2 is a sequential fp64 sum: recompute it the same way
-        for (int d0 = 0; d0 < a.D; ++d0) nq = fma((double)qr[d0], (double)qr[d0], nq);
+        // the oracle's |q|^2 is a sequential fp64 sum: recompute it the same way (from the copy in LDS, four
+        // elements per read: a loop over the row in memory costs a load latency per element)
+        int d0 = 0;
+        for (; d0 + 4 <= a.D; d0 += 4) {
+            const float4 v = *(const float4*)(qs + d0);
+            nq = fma((double)v.x, (double)v.x, nq);
+            nq = fma((double)v.y, (double)v.y, nq);
+            nq = fma((double)v.z, (double)v.z, nq);
+            nq = fma((double)v.w, (double)v.w, nq);
+        }
+        for (; d0 < a.D; ++d0) nq = fma((double)qs[d0], (double)qs[d0], nq);
     }
     int done = 0;                       // candidates [0, done) are re-scored
-    int want = c < HRS_RESCORE ? c : HRS_RESCORE;
+    // first round: the rows that must be re-scored for a proof are those whose recorded bound reaches the k-th best
+    // exact score -- for the int8 shadow several times k, rarely more than 8 k + 48
+    int first = (8 * a.k + 48 + 63) & ~63;
+    if (first > HRS_RESCORE) first = HRS_RESCORE;
+    int want = c < first ? c : first;
     bool accept = false, defer = false;
+#ifdef HRS_SEL_PROF
+    const long long pt_init = wall_clock64() - pt0;
+#endif
     while (true) {
+#ifdef HRS_SEL_PROF
+        const long long pr0 = wall_clock64();
+#endif
         // Re-score candidates [done, want): thread t owns candidate done + t (one fp64 chain per row, the
         // oracle's operation order).  The rows are fetched by the wave together -- eight lanes per row, a
         // 128-byte line per row and instruction -- into a per-wave LDS block and read back row-wise
@@ -1125,19 +1165,22 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
             // (a thread without a candidate still helps to fetch: it points at the first row)
             const float* cr = live ? a.C + (size_t)((int64_t)grow - a.row_offset) * a.D : a.C;
             // pointer of the row that this lane helps to fetch in instruction j: row (8j + lane/8) of the wave
-            const char* fp[8];
+            // (typed as global memory: a pointer rebuilt from integers would otherwise be loaded from with flat
+            // instructions, which count as LDS operations too and would make every LDS wait a memory wait)
+            typedef const __attribute__((address_space(1))) char* gptr;
+            gptr fp[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int src = 8 * j + (lane >> 3);
                 const uint64_t v = (uint64_t)cr;
                 const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
-                fp[j] = (const char*)(((uint64_t)hi << 32) | lo) + (lane & 7) * 16;
+                fp[j] = (gptr)(((uint64_t)hi << 32) | lo);
             }
             char* wl = stage + (tid >> 6) * (64 * 144);
             char* wr_base = wl + (lane >> 3) * 144 + (lane & 7) * 16;
             const char* rd_base = wl + lane * 144;
             double acc = 0.0, nc = 0.0;
-            auto step4 = [&](const float4 cv, const float4 qv) __attribute__((always_inline)) {
+            auto step4 = [&](const f32x4 cv, const float4 qv) __attribute__((always_inline)) {
                 const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
                 const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
                 if (SPACE == HRS_SPACE_L2) {
@@ -1159,25 +1202,39 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
                     }
                 }
             };
+            // A window of SEL_PF 128-byte chunks per row is in flight (in registers) while one is consumed: a round
+            // costs about one memory latency instead of one per chunk.  No request is conditional -- a piece beyond
+            // the row's end is replaced by the row's last piece, which nobody reads back -- so the loop body has no
+            // branch around a load and the compiler's waits stay counted.
+            constexpr int SEL_PF = 4;
             const int nchunk = (a.D + 31) >> 5;
-            float4 nxt[8];
-            auto fetch = [&](int c) __attribute__((always_inline)) {
-                const bool on = c * 32 + (lane & 7) * 4 < a.D;  // this lane's 16-byte piece exists in the chunk
+            const int last_piece = a.D * 4 - 16;
+            f32x4 nxt[SEL_PF][8];
+            auto fetch = [&](int c, f32x4 (&dst)[8]) __attribute__((always_inline)) {
+                const int off = min(c * 128 + (lane & 7) * 16, last_piece);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) nxt[j] = on ? *(const float4*)(fp[j] + c * 128) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < 8; ++j) dst[j] = *(const __attribute__((address_space(1))) f32x4*)(fp[j] + off);
             };
-            fetch(0);
-            for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *(float4*)(wr_base + j * (8 * 144)) = nxt[j];
-                if (c + 1 < nchunk) fetch(c + 1);  // in flight under this chunk's arithmetic
-                // only this wave touches its block: LDS operations of a wave complete in order
-                const int np = min(8, (a.D - c * 32) >> 2);
-                if (np == 8) {
+            for (int p = 0; p < SEL_PF; ++p) {
+                fetch(p, nxt[p]);
+                __builtin_amdgcn_sched_barrier(0);  // in this order: the first chunk is awaited first
+            }
+            for (int c0 = 0; c0 < nchunk; c0 += SEL_PF) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) step4(*(const float4*)(rd_base + u * 16), *(const float4*)(qs + c * 32 + 4 * u));
-                } else {
-                    for (int u = 0; u < np; ++u) step4(*(const float4*)(rd_base + u * 16), *(const float4*)(qs + c * 32 + 4 * u));
+                for (int p = 0; p < SEL_PF; ++p) {
+                    const int c = c0 + p;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) *(f32x4*)(wr_base + j * (8 * 144)) = nxt[p][j];
+                    fetch(c + SEL_PF, nxt[p]);
+                    // only this wave touches its block: LDS operations of a wave complete in order
+                    const int np = min(8, (a.D - c * 32) >> 2);
+                    if (np == 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) step4(*(const f32x4*)(rd_base + u * 16), *(const float4*)(qs + c * 32 + 4 * u));
+                    } else {
+                        for (int u = 0; u < np; ++u) step4(*(const f32x4*)(rd_base + u * 16), *(const float4*)(qs + c * 32 + 4 * u));
+                    }
                 }
             }
             if (live) {
@@ -1191,12 +1248,17 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
                 ek[idx] = pack_key((float)d, grow);
             }
         }
+#ifdef HRS_SEL_PROF
+        const long long pr1 = wall_clock64();
+        pt_resc += pr1 - pr0;
+        pt_rounds += 1;
+#endif
         done = want;
         if (tid == 0) need_s = 0;
         {
             int en = 256;
             while (en < done) en <<= 1;
-            bitonic_sort_u64(ek, en, tid, 256);  // (its barriers also publish need_s)
+            sort_keys(ek, en);  // (its barriers also publish need_s)
         }
         if (overflow || done < a.k) break;
         const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
@@ -1224,6 +1286,14 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         want = need < done + HRS_RESCORE ? need : done + HRS_RESCORE;
         if (want > RMAX) want = RMAX;
     }
+#ifdef HRS_SEL_PROF
+    if (tid == 0) {
+        atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)pt_init);
+        atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)pt_resc);
+        atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)(wall_clock64() - pt0));
+        atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)pt_rounds);
+    }
+#endif
     if (tid == 0) {
         ok = accept;
         atomicMax((unsigned long long*)&a.stats[1], (unsigned long long)craw);
@@ -1239,7 +1309,11 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     }
     __syncthreads();
     if (ok)
-        for (int t = tid; t < a.k; t += 256) a.keys_out[(size_t)q * a.k + t] = ek[t];
+        for (int t = tid; t < a.k; t += 256) {
+            const uint64_t key = ek[t];
+            a.keys_out[(size_t)q * a.k + t] = key;
+            hrs_store_unpacked(key, (size_t)q * a.k + t, a.dist_out, a.rows_out);
+        }
 }
 
 template <int KS, int TR, bool I8, int QT, bool RS>
@@ -1305,7 +1379,7 @@ static int scan_mark_done(hrs_ctx* ctx, hipStream_t st) {
 }
 
 int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
-                    uint64_t* keys_out, hipStream_t st, int phase) {
+                    uint64_t* keys_out, hipStream_t st, int phase, hrs_unpacked un) {
     const bool do_scan = phase != HRS_PHASE_TAIL, do_tail = phase != HRS_PHASE_SCAN;
     if (phase != HRS_PHASE_ALL && (!c->shadow || ctx->num_cu != HRS_NUM_CU || B > 1024)) {
         hrs_set_error("hrs_launch_mfma: a two-phase call needs a shadow and at most 1024 queries");
@@ -1313,7 +1387,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     }
     if (!c->shadow || ctx->num_cu != HRS_NUM_CU) {
         // no matrix-core kernel for this shape: the exact scan gives the same answer
-        return hrs_launch_exact(ctx, c, Q, B, k, space, mask, nullptr, nullptr, keys_out, st);
+        return hrs_launch_exact(ctx, c, Q, B, k, space, mask, nullptr, nullptr, keys_out, st, nullptr, 0, -1, 0, un);
     }
     const bool i8 = c->kind == HRS_SHADOW_I8;
     const int Dpad = c->Dpad, KS = i8 ? Dpad / 32 : Dpad / 16;
@@ -1333,6 +1407,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_qn = carve((size_t)BC * sizeof(double));
     const size_t o_max = carve((size_t)BC * HRS_MAX_STREAMS * sizeof(float));
     const size_t o_tau = carve((size_t)BC * sizeof(float));
+    const size_t o_tau2 = carve((size_t)BC * sizeof(float));
     const size_t o_cnt = carve((size_t)BC * sizeof(int));
     const size_t o_qs = carve((size_t)BC * sizeof(float));
     const size_t o_kq = carve((size_t)BC * sizeof(float));
@@ -1394,6 +1469,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.ss = ss;
         a.maxima = (float*)(ws + o_max);
         a.tau = (const float*)(ws + o_tau);
+        a.tau_out = (float*)(ws + o_tau2);
+        a.raise_limit = HRS_CAND_CAP_BIG / 4;
         a.cnt = (int*)(ws + o_cnt);
         a.cand = (uint64_t*)(ws + o_cand);
         a.mask = mask;
@@ -1409,7 +1486,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         if (j < HRS_J_MIN) j = HRS_J_MIN;
         if (j > M / 2) j = M / 2;
 
-        // sampled maxima -> first tau -> sampled ladder counts -> tau raised where rows come in runs -> scan
+        // sampled maxima -> first tau -> sampled ladder counts -> scan (tau raised where rows come in runs)
         auto tau_steps = [&](auto&& scan) -> int {
             int r = scan(1);
             if (r) return r;
@@ -1418,11 +1495,10 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             // the ladder only has to be right within a factor of two: half the sample of the first pass
             const int ss2 = (int64_t)2 * ss * 4 <= min_len ? 2 * ss : ss;
             a.ss = ss2;
+            a.raise_ss = ss2;
             r = scan(2);
             a.ss = ss;
             if (r) return r;
-            hipLaunchKernelGGL(k_raise_tau, dim3((bpad + 255) / 256), dim3(256), 0, st, (float*)(ws + o_tau),
-                               (const float*)(ws + o_lad), (const int*)(ws + o_hist), bpad, ss2, HRS_CAND_CAP_BIG / 4);
             if (phase == HRS_PHASE_SCAN && ctx->pre_done) {
                 HRS_CHECK_HIP(hipEventRecord(ctx->pre_done, st));
                 ctx->pre_recorded = true;
@@ -1498,12 +1574,14 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.k = k;
         s.cnt = a.cnt;
         s.cand = a.cand;
-        s.tau = a.tau;
+        s.tau = a.tau_out;
         s.qn2 = (const double*)(ws + o_qn);
         s.norm_stats = c->norm_stats;
         s.eps_rel = MF_EPS_BASE + MF_EPS_PER_D * Dpad;
         s.qscale = i8 ? (const float*)(ws + o_qs) : nullptr;
         s.keys_out = keys_out;
+        s.dist_out = un.dist;
+        s.rows_out = un.rows;
         s.qlist = qlist;
         s.nflag = nflag;
         s.stats = (long long*)ctx->stats_dev;
@@ -1521,5 +1599,5 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     }
     if (!do_tail) return HRS_OK;
     // queries that could not be proven take the exact scan (device-side count; usually zero)
-    return hrs_launch_exact(ctx, c, Q, B, k, space, mask, qlist, nflag, keys_out, st);
+    return hrs_launch_exact(ctx, c, Q, B, k, space, mask, qlist, nflag, keys_out, st, nullptr, 0, -1, 0, un);
 }
