@@ -103,13 +103,13 @@ extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : HRS_NUM_CU;
     c->scan_qt1 = getenv("HRS_SCAN_QT1") != nullptr;
-    hipError_t e = hipMalloc((void**)&c->stats_dev, 8 * sizeof(int64_t));
+    hipError_t e = hipMalloc((void**)&c->stats_dev, 16 * sizeof(int64_t));
     if (e != hipSuccess) {
         delete c;
         hrs_set_error("hrs_ctx_create: hipMalloc failed: %s", hipGetErrorString(e));
         return HRS_ERR_NOMEM;
     }
-    e = hipMemset(c->stats_dev, 0, 8 * sizeof(int64_t));
+    e = hipMemset(c->stats_dev, 0, 16 * sizeof(int64_t));
     if (e != hipSuccess) {
         (void)hipFree(c->stats_dev);
         delete c;
@@ -374,6 +374,14 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     out[0] = h[0];
     out[1] = h[1];
     out[2] = h[2];
+#ifdef HRS_SCAN_PROF
+    {
+        int64_t g[16];
+        HRS_CHECK_HIP(hipMemcpy(g, ctx->stats_dev, sizeof(g), hipMemcpyDeviceToHost));
+        fprintf(stderr, "scan per WG (us): prologue %.2f first-tile %.2f loop %.2f flush %.2f | start skew %.2f, first loop end after %.2f, last end after %.2f\n",
+                g[4] / 25600.0, g[5] / 25600.0, g[6] / 25600.0, g[7] / 25600.0, (g[9] - g[8]) / 100.0, (g[10] - g[8]) / 100.0, (g[11] - g[8]) / 100.0);
+    }
+#endif
 #ifdef HRS_SEL_PROF
     fprintf(stderr, "select: init %lld resc %lld total %lld (x10 ns, summed over queries) rounds %lld maxcand %lld\n", (long long)h[4], (long long)h[5], (long long)h[6], (long long)h[7], (long long)h[1]);
 #endif

@@ -71,12 +71,25 @@ constexpr size_t scan_lds_bytes(int tile_bytes, bool pair) {
     return (size_t)scan_nbuf(tile_bytes, pair ? 2 : 1) * tile_bytes + (size_t)scan_stage(pair) * 12;
 }
 #define MF_QPB 256   // queries per workgroup and 32-query tile of a wave (QT tiles per wave)
+// The per-query list lengths sit one to a 128-byte line: atomics on one line are served one after the other, and
+// with sixteen or thirty-two counters to a line the final flush of a small-corpus pass (every wave appends at the
+// same moment) queued for longer than it took to stream a sixth of the corpus.
+#define MF_CNT_STRIDE 32
 #define MF_EPS_BASE 0.0039101
 #define MF_EPS_PER_D 2.4e-7
 
+// The converted queries are stored fragment-major: the 16-byte pieces that the 64 lanes of a wave load as one
+// operand fragment (32 queries x the two halves of a 32-byte k-step) are contiguous, 1 KB per (32 queries, k-step).
+// Row-major, a fragment load touched 32 cache lines for 32 bytes each, a wave's 24 to 64 KB of query rows thrashed
+// the 16 KB vector cache between k-steps, and all 256 workgroups asked the same L2 channels for the same lines at
+// the same moment: the start of every pass took 5 us for that alone.
+__device__ __forceinline__ size_t qfrag_offset(int q, int kstep, int half, int ksteps) {
+    return ((size_t)(q >> 5) * ksteps + kstep) * 1024 + half * 512 + (q & 31) * 16;
+}
+
 struct MfmaArgs {
     const char* shadow;    // [Npad][KS * 32 bytes]
-    const char* qb;        // [Bpad][KS * 32 bytes]
+    const char* qb;        // [Bpad / 32][KS][2][32][16 bytes], see qfrag_offset
     const float2* group;   // int8 only, per 32-row group: (s_g, M_g) for PRE, (1 / s_g, M_g) for MAIN
     const float* kq;       // int8 only, per query: K_q
     int64_t N;
@@ -93,8 +106,11 @@ struct MfmaArgs {
     float* tau_out;        // [Bpad] MODE 0: the threshold the pass filtered by (raised where the ladder says so)
     int raise_ss;          // MODE 0: sampling stride of the ladder pass
     int raise_limit;       // MODE 0: estimated rows above the threshold that a list may hold
-    int* cnt;              // [Bpad]
+    int* cnt;              // [Bpad * MF_CNT_STRIDE], one counter per 128-byte line
     uint64_t* cand;        // [Bpad][HRS_CAND_CAP_BIG]
+#ifdef HRS_SCAN_PROF
+    long long* prof;
+#endif
 };
 
 // Rows of a topically ordered corpus do not score independently: whole runs of neighbours exceed the first
@@ -176,33 +192,40 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     const int sb0 = RS ? (wv >> 2) : 0;       // first 32-row group of a tile that this wave scores
     const int q0 = RS ? qg * MF_QPB + (wv & 3) * MF_QPW : qg * (MF_QPB * QT) + wv * MF_QPW;
 
+#ifdef HRS_SCAN_PROF
+    const long long pt0 = wall_clock64();
+    long long pt1 = pt0, pt2 = pt0, pt3 = pt0;
+#endif
+    // The queries of this wave: fragments, thresholds and error terms.  Requested right behind the first corpus tile
+    // (the requests are independent, and a pass over a small corpus is short enough for a serial start to show).
     frag_t qf[QT][KS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            qf[qt][s] = *(const frag_t*)(a.qb + (size_t)(q0 + qt * 32 + i) * RB + s * 32 + h * 16);
-
     float tau[QT], kq[QT], linv[QT];
     float mx[QT][WSUB];
+    auto load_queries = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        tau[qt] = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + qt * 32 + i] : raised_tau(a, q0 + qt * 32 + i));
-        if (MODE == 0 && slice == 0 && sb0 == 0 && h == 0) a.tau_out[q0 + qt * 32 + i] = tau[qt];  // one writer per query
-        kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
-        linv[qt] = LADDER ? a.lad_inv[q0 + qt * 32 + i] : 0.f;
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int sb = 0; sb < WSUB; ++sb) mx[qt][sb] = -__builtin_inff();
-    }
-    // every query fragment must have landed before the loop: the compiler would otherwise place its
-    // partial vmcnt waits at their first use inside the loop, where they would drain the LDS-DMA ring
+            for (int s = 0; s < KS; ++s)
+                qf[qt][s] = *(const frag_t*)(a.qb + qfrag_offset(q0 + qt * 32 + i, s, h, KS));
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt) {
+            tau[qt] = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + qt * 32 + i] : raised_tau(a, q0 + qt * 32 + i));
+            if (MODE == 0 && slice == 0 && sb0 == 0 && h == 0) a.tau_out[q0 + qt * 32 + i] = tau[qt];  // one writer per query
+            kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
+            linv[qt] = LADDER ? a.lad_inv[q0 + qt * 32 + i] : 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
+            for (int sb = 0; sb < WSUB; ++sb) mx[qt][sb] = -__builtin_inff();
+        }
+        // every query fragment must have landed before the loop: the compiler would otherwise place its
+        // partial vmcnt waits at their first use inside the loop, where they would drain the LDS-DMA ring
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]), "+v"(linv[qt]));
-    if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]), "+v"(linv[qt]));
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
+    };
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     int wcnt = 0;  // entries staged (wave-uniform)
     auto to_memory = [&](uint64_t key, int q) __attribute__((always_inline)) {
         if (!a.mask || a.mask[(int64_t)(uint32_t)key - a.row_offset]) {  // the `where` filter
-            const int pos = atomicAdd(&a.cnt[q], 1);
+            const int pos = atomicAdd(&a.cnt[q * MF_CNT_STRIDE], 1);
             if (pos < HRS_CAND_CAP_BIG) a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] = key;
         }
     };
@@ -289,12 +312,22 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(scn[0]) : "s"(p));
             }
         };
+#ifdef HRS_SCAN_PROF
+        pt1 = wall_clock64();
+#endif
         if (I8) scale_load(tile_at(0));
+        // first tile, queries, rest of the ring: requests come back in order, and behind the whole ring (120 KB per
+        // CU, 30 MB over the chip) the queries would arrive 5 us later than behind one tile
+        issue(0, 0);
+        load_queries();
 #pragma unroll
-        for (int g = 0; g < NBUF; ++g) issue(g, g);
+        for (int g = 1; g < NBUF; ++g) issue(g, g);
         // the first tile (PAIR: the first two) has landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PAIR ? NBUF - 2 : NBUF - 1) * IPW) : "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef HRS_SCAN_PROF
+        pt2 = wall_clock64();
+#endif
         int buf = 0;
         if (q0 >= a.nq) {
             // padding queries only (a small batch): this wave keeps its share of the LDS-DMA ring going and
@@ -454,9 +487,27 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
             }
         }
         }  // waves with queries
+#ifdef HRS_SCAN_PROF
+        pt3 = wall_clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (MODE == 0) flush_wave();  // what is still staged
+    } else {
+        load_queries();  // (for the threshold that the first slice publishes)
     }
+#ifdef HRS_SCAN_PROF
+    if (MODE == 0 && lane == 0 && wv == 0) {
+        unsigned long long* st = (unsigned long long*)a.prof;
+        atomicAdd(&st[4], (unsigned long long)(pt1 - pt0));
+        atomicAdd(&st[5], (unsigned long long)(pt2 - pt1));
+        atomicAdd(&st[6], (unsigned long long)(pt3 - pt2));
+        atomicAdd(&st[7], (unsigned long long)(wall_clock64() - pt3));
+        atomicMin(&st[8], (unsigned long long)pt0);
+        atomicMax(&st[9], (unsigned long long)pt0);
+        atomicMin(&st[10], (unsigned long long)pt3);
+        atomicMax(&st[11], (unsigned long long)wall_clock64());
+    }
+#endif
     if (MAXIMA) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
@@ -497,21 +548,27 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
     const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
     const int q0 = qg * 128 + wv * 32;
 
+    // this wave's queries: requested right behind the first corpus stage (independent requests; a short pass
+    // shows a serial start)
     bf16x8 qf[SPT * KSS];
-#pragma unroll
-    for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + ((size_t)(q0 + i) * DP + s * 16 + h * 8) * 2);
-    const float tau = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + i] : raised_tau(a, q0 + i));
-    if (MODE == 0 && slice == 0 && h == 0) a.tau_out[q0 + i] = tau;  // one writer per query
-    const float linv = LADDER ? a.lad_inv[q0 + i] : 0.f;
+    float tau = 0.f, linv = 0.f;
     float mx = -__builtin_inff();
+    auto load_queries = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < SPT * KSS; ++s) {
-        if (s < NA)
-            asm volatile("" : "+a"(qf[s]));
-        else
-            asm volatile("" : "+v"(qf[s]));
-    }
-    if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
+        for (int s = 0; s < SPT * KSS; ++s) qf[s] = *(const bf16x8*)(a.qb + qfrag_offset(q0 + i, s, h, SPT * KSS));
+        tau = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + i] : raised_tau(a, q0 + i));
+        if (MODE == 0 && slice == 0 && h == 0) a.tau_out[q0 + i] = tau;  // one writer per query
+        linv = LADDER ? a.lad_inv[q0 + i] : 0.f;
+#pragma unroll
+        for (int s = 0; s < SPT * KSS; ++s) {
+            if (s < NA)
+                asm volatile("" : "+a"(qf[s]));
+            else
+                asm volatile("" : "+v"(qf[s]));
+        }
+        asm volatile("" : "+v"(tau), "+v"(linv));
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
+    };
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
@@ -551,7 +608,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
         // the previous tile are requested anew.  Small batches are bound by the bytes in flight and keep the
         // per-stage barrier with three stages outstanding.
         const bool pairs = a.nq >= 512;
-        issue(0);
+        issue(0);  // first stage, queries, rest of the ring: requests come back in order
+        load_queries();
         issue(1);
         if (!pairs) issue(2);
         f32x16 acc;
@@ -613,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
                         if (acc[r] > tau) {
                             const int64_t row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                             if (row < a.N && (!a.mask || a.mask[row])) {
-                                const int pos = atomicAdd(&a.cnt[q], 1);
+                                const int pos = atomicAdd(&a.cnt[q * MF_CNT_STRIDE], 1);
                                 if (pos < HRS_CAND_CAP_BIG)
                                     a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] =
                                         ((uint64_t)(~f32_orderable(acc[r])) << 32) | (uint32_t)(row + a.row_offset);
@@ -623,6 +681,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
                 }
             }
         }
+    } else {
+        load_queries();  // (for the threshold that the first slice publishes)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MAXIMA) a.maxima[(size_t)(q0 + i) * HRS_MAX_STREAMS + slice * 2 + h] = mx;
@@ -932,7 +992,7 @@ __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ 
     for (int c = lane; c < Dpad; c += 64) {
         const float v = (q < B && c < D) ? Q[(size_t)q * D + c] : 0.f;
         const int qi = sq > 0.f ? (int)rintf(v / sq) : 0;
-        qb[(size_t)q * Dpad + c] = (int8_t)qi;
+        qb[qfrag_offset(q, c >> 5, (c >> 4) & 1, Dpad >> 5) + (c & 15)] = (int8_t)qi;
         l1 += abs(qi);
         ss += (double)v * (double)v;
     }
@@ -957,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_convert_q(const float* __restrict__ Q, 
     double ss = 0.0;
     for (int c = lane; c < Dpad; c += 64) {
         float v = (q < B && c < D) ? Q[(size_t)q * D + c] : 0.f;
-        qb[(size_t)q * Dpad + c] = (__bf16)v;
+        *(__bf16*)((char*)qb + qfrag_offset(q, c >> 4, (c >> 3) & 1, Dpad >> 4) + (c & 7) * 2) = (__bf16)v;
         ss += (double)v * (double)v;
     }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
@@ -1024,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxi
         const float v = orderable_f32(~prefix);
         const float top = orderable_f32(~min(min(smin[0], smin[1]), min(smin[2], smin[3])));
         tau[q] = v;
-        cnt[q] = 0;
+        cnt[q * MF_CNT_STRIDE] = 0;
         lad_inv[q] = (top > v && top - v < 1e30f) ? 16.0f / (top - v) : 0.f;
     }
 }
@@ -1084,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     }
     const int q = a.qbase + ql;      // query in the caller's batch
     const int tid = threadIdx.x;
-    const int craw = a.cnt[ql];
+    const int craw = a.cnt[ql * MF_CNT_STRIDE];
     const int c = craw < SCAP ? craw : SCAP;
     const bool overflow = craw > HRS_CAND_CAP_BIG;  // rows above tau were dropped: only the exact scan can answer
     if (!BIG && craw > SCAP && !overflow) {         // longer than this variant sorts: the large one takes it
@@ -1408,7 +1468,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_max = carve((size_t)BC * HRS_MAX_STREAMS * sizeof(float));
     const size_t o_tau = carve((size_t)BC * sizeof(float));
     const size_t o_tau2 = carve((size_t)BC * sizeof(float));
-    const size_t o_cnt = carve((size_t)BC * sizeof(int));
+    const size_t o_cnt = carve((size_t)BC * MF_CNT_STRIDE * sizeof(int));
     const size_t o_qs = carve((size_t)BC * sizeof(float));
     const size_t o_kq = carve((size_t)BC * sizeof(float));
     const size_t o_lad = carve((size_t)BC * sizeof(float));
@@ -1463,13 +1523,16 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.nqg = nqg;
         a.nq = bc;
         const int64_t min_len = tiles / nslices;  // shortest slice, in tiles
-        int ss = (int)(min_len / 8);
+        int ss = (int)(min_len / 4);  // at least four sampled tiles per slice
         if (ss > HRS_SS_MAX) ss = HRS_SS_MAX;
         if (ss < 1) ss = 1;
         a.ss = ss;
         a.maxima = (float*)(ws + o_max);
         a.tau = (const float*)(ws + o_tau);
         a.tau_out = (float*)(ws + o_tau2);
+#ifdef HRS_SCAN_PROF
+        a.prof = (long long*)ctx->stats_dev;
+#endif
         a.raise_limit = HRS_CAND_CAP_BIG / 4;
         a.cnt = (int*)(ws + o_cnt);
         a.cand = (uint64_t*)(ws + o_cand);
@@ -1505,10 +1568,20 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             }
             return HRS_OK;
         };
+#ifdef HRS_SCAN_PROF
+#define HRS_SCAN_PROF_RESET                                                    \
+    (void)hipMemsetAsync(ctx->stats_dev + 8, 0xFF, 8, st);                     \
+    (void)hipMemsetAsync(ctx->stats_dev + 9, 0, 8, st);                        \
+    (void)hipMemsetAsync(ctx->stats_dev + 10, 0xFF, 8, st);                    \
+    (void)hipMemsetAsync(ctx->stats_dev + 11, 0, 8, st);
+#else
+#define HRS_SCAN_PROF_RESET
+#endif
 #define HRS_SCAN(KS_, TR_, I8_)                                                                      \
     case KS_: {                                                                                      \
         auto scan = [&](int mode) { return launch_scan<KS_, TR_, I8_>(a, mode, qt, c, ctx->device, st); };        \
         if ((rc = tau_steps(scan))) return rc;                                                       \
+        HRS_SCAN_PROF_RESET                                                                          \
         hrs_prof_begin(ctx, st);                                                                     \
         rc = scan(0);                                                                                \
         hrs_prof_end(ctx, st);                                                                       \

@@ -1,3 +1,7 @@
+"""Where the time of a small-batch scoring call goes INSIDE the kernels: per-workgroup phases of the main scan pass
+and per-query phases of the re-score kernel, from clock reads compiled in by `make -C hybrid_rag_system_amd/csrc prof`
+(libhrs_prof.so; the shipped library carries none of this).  The figures are printed to stderr by hrs_score_stats.
+usage: HRS_LIBRARY=$PWD/hybrid_rag_system_amd/libhrs_prof.so python tools/scan_phases.py"""
 import sys
 sys.path.insert(0, '.')
 import torch
