@@ -1128,7 +1128,7 @@ struct SelectArgs {
 // the prefix -- recorded or never recorded (score <= tau) -- can; otherwise queue the query for the
 // exact scan.
 template <int SPACE, bool BIG>
-__global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
+__device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) {  // ql: query within the chunk
     constexpr int SCAP = BIG ? HRS_CAND_CAP_BIG : HRS_CAND_CAP;  // candidates sorted in LDS
     constexpr int RMAX = BIG ? 4096 : HRS_RESCORE_MAX;           // largest re-scored prefix
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
@@ -1137,11 +1137,6 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
     float* qs = (float*)(ek + RMAX);                         // [1024] the query (D <= 1024 on this path)
     char* stage = (char*)(qs + 1024);                        // per wave: 64 rows x one 128-byte line (+16 pad)
     __shared__ int need_s, ok;
-    int ql = blockIdx.x;             // query within the chunk
-    if (BIG) {
-        if ((int)blockIdx.x >= *a.nflag2) return;
-        ql = a.qlist2[blockIdx.x];
-    }
     const int q = a.qbase + ql;      // query in the caller's batch
     const int tid = threadIdx.x;
     const int craw = a.cnt[ql * MF_CNT_STRIDE];
@@ -1376,6 +1371,22 @@ __global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
         }
 }
 
+// The small variant: one workgroup per query.  The large one: a grid of at most one workgroup per CU walks the queue of
+// deferred queries (device-side count, nearly always zero -- and a thousand workgroups of 100 KB of LDS each are slow
+// to dispatch and retire beside a scan even when they leave at once).
+template <int SPACE, bool BIG>
+__global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
+    if (!BIG) {
+        select_rescore_one<SPACE, false>(a, blockIdx.x);
+    } else {
+        const int n = *a.nflag2;
+        for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+            select_rescore_one<SPACE, true>(a, a.qlist2[slot]);
+            __syncthreads();
+        }
+    }
+}
+
 template <int KS, int TR, bool I8, int QT, bool RS>
 static int launch_scan_qt(const MfmaArgs& a, int mode, int device, hipStream_t st) {
     const size_t lds = scan_lds_bytes(TR * KS * 32, scan_pairs(QT) && !RS);
@@ -1424,7 +1435,7 @@ static int launch_select(const SelectArgs& s, int bc, int device, hipStream_t st
     }
     hipLaunchKernelGGL((k_select_rescore<SPACE, false>), dim3(bc), dim3(256), lds_small, st, s);
     // deferred queries (device-side count; workgroups beyond it leave at once)
-    hipLaunchKernelGGL((k_select_rescore<SPACE, true>), dim3(bc), dim3(256), lds_big, st, s);
+    hipLaunchKernelGGL((k_select_rescore<SPACE, true>), dim3(bc < HRS_NUM_CU ? bc : HRS_NUM_CU), dim3(256), lds_big, st, s);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
@@ -1483,9 +1494,12 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
 
     const int64_t tiles = (c->N + TR - 1) / TR;
     if (do_scan && ctx->peer && ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
-    // the tail of a two-phase call starts once the scan that waits for this one has set its thresholds: it then
-    // runs under that scan's main pass instead of beside its sampled passes
-    if (phase == HRS_PHASE_TAIL && ctx->waiter && ctx->waiter->pre_recorded)
+    // The tail of a two-phase call runs right behind its own main pass, beside the sampled passes of the scan that
+    // waits for this one.  (HRS_TAIL_LATE=1 holds it until that scan has set its thresholds, so that it is queued
+    // under that scan's main pass; it cannot share a SIMD with two scan waves -- 2 x 200 + 128 registers -- and when
+    // it is made to fit, the main pass loses more than the tail takes by itself.)
+    static const bool tail_late = getenv("HRS_TAIL_LATE") != nullptr;
+    if (tail_late && phase == HRS_PHASE_TAIL && ctx->waiter && ctx->waiter->pre_recorded)
         HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->waiter->pre_done, 0));
     for (int qbase = 0; qbase < B; qbase += BC) {
         const int bc = B - qbase < BC ? B - qbase : BC;
