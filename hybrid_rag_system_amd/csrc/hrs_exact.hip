@@ -46,10 +46,22 @@ struct ExactArgs {
     const uint64_t* after;  // nullable, per query: only keys strictly above it are eligible (a search resumed behind its last result)
     uint64_t* partial;  // [nq][gridDim.x][k]
     int64_t tiles;
+    const double* qd;   // SQ kernels: the queries as fp64, [nq][D] (written by k_queries_f64 before the scan)
 };
 
-template <int SPACE, int BQ>
+// fp32 -> fp64 copy of the queries for the scan kernels that take them through the scalar cache
+__global__ void k_queries_f64(const float* __restrict__ Q, int64_t n, double* __restrict__ qd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) qd[i] = (double)Q[i];
+}
+
+// SQ: the queries' values come from a.qd through the scalar cache instead of from an fp64 copy in LDS.  With four
+// queries per pass the LDS copy costs 64 of the 72 LDS reads per thread and 32-float segment -- every lane reads the
+// same 16 bytes, but a read instruction takes its share of the LDS pipe all the same -- and held the scan at 4.1 TB/s
+// where the same loop without them streams 5.8.
+template <int SPACE, int BQ, bool SQ = false>
 __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
+    typedef const __attribute__((address_space(4))) double* qd_ptr;
     constexpr int NQT = BQ > ESLOTS ? BQ / ESLOTS : 1;  // queries per thread
     constexpr int NSL = BQ < ESLOTS ? BQ : ESLOTS;      // query slots in use
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,8 +113,13 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             qnorm[tid] = s;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the compiler's is in flight past here
+        qd_ptr qrow[NQT];  // SQ: this thread's queries (wave-uniform: a wave lies within one query slot)
+#pragma unroll
+        for (int b = 0; b < NQT; ++b)
+            qrow[b] = SQ ? (qd_ptr)(uintptr_t)uniform_ptr(a.qd + (size_t)__builtin_amdgcn_readfirstlane(qidx[qslot + NSL * b]) * D) : (qd_ptr)(uintptr_t)0;
 
         auto stage_q = [&](int ch, int buf) {  // LDS fp32 -> LDS fp64, this chunk of every query of the pass
+            if (SQ) return;
             const int w = min(EDC, D - ch * EDC);
             for (int e = tid; e < BQ * EDC; e += 256) {
                 const int b = e / EDC, i = e % EDC;
@@ -176,7 +193,15 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
 #pragma unroll
                     for (int b = 0; b < NQT; ++b) {
                         const double* qp = qb + (qslot + NSL * b) * EDC + s * 4;
-                        const double q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+                        double q0, q1, q2, q3;
+                        if (SQ) {
+                            // wave-uniform values through the scalar cache: operands of the fp64 instructions straight
+                            // from scalar registers
+                            const qd_ptr qs = qrow[b] + ch * EDC + s * 4;
+                            q0 = qs[0], q1 = qs[1], q2 = qs[2], q3 = qs[3];
+                        } else {
+                            q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+                        }
                         if (SPACE == HRS_SPACE_L2) {
                             const double d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
                             acc[b] = fma(d0, d0, acc[b]);
@@ -191,7 +216,65 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                         }
                     }
                 };
-                if (pieces == EDC / 4) {
+                if (SQ && pieces == EDC / 4) {
+                    // Full segment, queries through the scalar cache.  The compiler would request all 256 scalar
+                    // registers' worth of a segment at once and park them in vector lanes; here two pieces of four
+                    // values per query are live: piece s + 1 is requested before piece s is used.  Scalar loads return
+                    // in any order, so the only wait is lgkmcnt(0) -- hence the row itself is read from LDS up front.
+                    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+                    float4 cv[EDC / 4];
+#pragma unroll
+                    for (int s = 0; s < EDC / 4; ++s) cv[s] = *(const float4*)(rowp + ((s ^ sw) << 4));
+                    u32x8 qv[2][NQT];
+                    auto request = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int b = 0; b < NQT; ++b)
+                            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(qv[s & 1][b]) : "s"(qrow[b] + ch * EDC + s * 4));
+                    };
+                    auto arrived = [&](int s) __attribute__((always_inline)) {
+                        if (NQT == 4)
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qv[s & 1][0]), "+s"(qv[s & 1][1]), "+s"(qv[s & 1][2]), "+s"(qv[s & 1][3]));
+                        else
+#pragma unroll
+                            for (int b = 0; b < NQT; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qv[s & 1][b]));
+                    };
+                    request(0);
+#pragma unroll
+                    for (int s = 0; s < EDC / 4; ++s) asm volatile("" : "+v"(cv[s].x), "+v"(cv[s].y), "+v"(cv[s].z), "+v"(cv[s].w));
+                    arrived(0);
+#pragma unroll
+                    for (int s = 0; s < EDC / 4; ++s) {
+                        if (s + 1 < EDC / 4) request(s + 1);
+                        const double c0 = (double)cv[s].x, c1 = (double)cv[s].y, c2 = (double)cv[s].z, c3 = (double)cv[s].w;
+                        if (SPACE == HRS_SPACE_COSINE) {
+                            ncacc = fma(c0, c0, ncacc);
+                            ncacc = fma(c1, c1, ncacc);
+                            ncacc = fma(c2, c2, ncacc);
+                            ncacc = fma(c3, c3, ncacc);
+                        }
+#pragma unroll
+                        for (int b = 0; b < NQT; ++b) {
+                            const u32x8 w = qv[s & 1][b];
+                            const double q0 = __builtin_bit_cast(double, ((uint64_t)w[1] << 32) | w[0]);
+                            const double q1 = __builtin_bit_cast(double, ((uint64_t)w[3] << 32) | w[2]);
+                            const double q2 = __builtin_bit_cast(double, ((uint64_t)w[5] << 32) | w[4]);
+                            const double q3 = __builtin_bit_cast(double, ((uint64_t)w[7] << 32) | w[6]);
+                            if (SPACE == HRS_SPACE_L2) {
+                                const double d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
+                                acc[b] = fma(d0, d0, acc[b]);
+                                acc[b] = fma(d1, d1, acc[b]);
+                                acc[b] = fma(d2, d2, acc[b]);
+                                acc[b] = fma(d3, d3, acc[b]);
+                            } else {
+                                acc[b] = fma(q0, c0, acc[b]);
+                                acc[b] = fma(q1, c1, acc[b]);
+                                acc[b] = fma(q2, c2, acc[b]);
+                                acc[b] = fma(q3, c3, acc[b]);
+                            }
+                        }
+                        if (s + 1 < EDC / 4) arrived(s + 1);
+                    }
+                } else if (pieces == EDC / 4) {
                     // full segment: unrolled, so the LDS reads of all 16 pieces are in flight together
 #pragma unroll
                     for (int s = 0; s < EDC / 4; ++s) piece(s);
@@ -340,23 +423,24 @@ __global__ __launch_bounds__(256) void k_merge_lists_serial(MergeArgs a) {
     }
 }
 
-template <int SPACE, int BQ>
+template <int SPACE, int BQ, bool SQ = false>
 static int launch_exact_t(const ExactArgs& a, int grid, int device, hipStream_t st) {
     size_t lds = ENBUF * ESEG_BYTES + EQ_FLOATS * sizeof(float) + 2 * BQ * EDC * sizeof(double) +
                  BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (2 * sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
     static hrs_per_device_once attr;  // the attribute belongs to the function on ONE device
     if (attr.need(device)) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ, SQ>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.done(device);
     }
-    hipLaunchKernelGGL((k_exact_scan<SPACE, BQ>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_exact_scan<SPACE, BQ, SQ>), dim3(grid), dim3(256), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
 
 template <int SPACE>
 static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipStream_t st) {
+    if (bq >= 4 && a.qd) return launch_exact_t<SPACE, 4, true>(a, grid, device, st);
     if (bq >= 4) return launch_exact_t<SPACE, 4>(a, grid, device, st);
     if (bq >= 2) return launch_exact_t<SPACE, 2>(a, grid, device, st);
     return launch_exact_t<SPACE, 1>(a, grid, device, st);
@@ -369,7 +453,7 @@ static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipS
 static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, uint64_t* p0, int grid, bool timed,
                      hipStream_t st, const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1,
-                     int64_t out_stride = 0, hrs_unpacked un = hrs_unpacked()) {
+                     int64_t out_stride = 0, hrs_unpacked un = hrs_unpacked(), double* qd = nullptr) {
     const int64_t tiles = (c->N + ER - 1) / ER;
     const int per = 16;
     const int g1 = (grid + per - 1) / per;
@@ -394,6 +478,14 @@ static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     a.tiles = tiles;
     int bq = nq_dev ? 4 : B;
     if (bq * c->D > EQ_FLOATS) bq = EQ_FLOATS / c->D;  // the pass's queries are staged in LDS as fp32
+    // passes of four queries take the queries' values through the scalar cache, from an fp64 copy (qd: room for B x D
+    // doubles; not for the queue of the matrix-core path, whose scan must cost nothing when the queue is empty)
+    a.qd = nullptr;
+    if (qd && !nq_dev && !qlist && bq >= 4 && c->N > 0) {
+        const int64_t n = (int64_t)B * c->D;
+        hipLaunchKernelGGL(k_queries_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Q, n, qd);
+        a.qd = qd;
+    }
     if (bq < 1) {
         hrs_set_error("exact scan: D=%d exceeds %d", c->D, EQ_FLOATS);
         return HRS_ERR_UNSUPPORTED;
@@ -461,10 +553,12 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
                      int64_t mask_qstride, int mask_eq, int64_t out_stride, hrs_unpacked un) {
     if (B <= 0) return HRS_OK;
     const int grid = exact_grid(ctx, c);
-    int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, exact_scratch_words(B, grid, k) * sizeof(uint64_t));
+    const size_t words = exact_scratch_words(B, grid, k), qd_words = nq_dev ? 0 : (size_t)B * c->D;
+    int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, (words + qd_words) * sizeof(uint64_t));
     if (rc) return rc;
-    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, (uint64_t*)ctx->ws_partial.ptr, grid, !nq_dev, st, after,
-                     mask_qstride, mask_eq, out_stride, un);
+    uint64_t* p0 = (uint64_t*)ctx->ws_partial.ptr;
+    return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, p0, grid, !nq_dev, st, after, mask_qstride, mask_eq,
+                     out_stride, un, qd_words ? (double*)(p0 + words) : nullptr);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------------
