@@ -122,8 +122,9 @@ class ShardedHybrid:
         e = self.engine
         q_terms, q_term_offs, n, boost = self._open
         self._open = None
-        _, rows, keys = e.score_topk_finish(want_keys=True)
+        cand_dist, rows, keys = e.score_topk_finish(want_keys=True)
         counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
+        local = (cand_dist, rows)  # the candidates unpacked, as the scoring call wrote them
         cuda = _is_cuda(e)
         xs = self.exchange_stream if (cuda and self.exchanges()) else None
         if xs is not None:
@@ -133,23 +134,25 @@ class ShardedHybrid:
                 t.record_stream(xs)  # allocated on the scan's stream, read on the exchange stream
             with torch.cuda.stream(xs):
                 xs.wait_event(ready)
-                out = self._exchange_and_fuse(keys, counts, q_term_offs, n, boost)
+                out = self._exchange_and_fuse(keys, counts, q_term_offs, n, boost, local)
                 self.done_event = torch.cuda.Event()
                 self.done_event.record()
             return out
-        out = self._exchange_and_fuse(keys, counts, q_term_offs, n, boost)
+        out = self._exchange_and_fuse(keys, counts, q_term_offs, n, boost, local)
         if cuda:
             self.done_event = torch.cuda.Event()
             self.done_event.record()
         return out
 
-    def _exchange_and_fuse(self, keys, counts, q_term_offs, n, boost):
+    def _exchange_and_fuse(self, keys, counts, q_term_offs, n, boost, local):
         e = self.engine
         if self.exchanges():
             self.bytes_gathered = keys.numel() * 16  # (key, count) as two int64 per candidate
             gk, gc = allgather_candidates(keys, counts, self.group)
             keys, counts = e.merge_topk(gk, gc)
-        cand_dist, cand_rows = e.unpack_keys(keys)
+            cand_dist, cand_rows = e.unpack_keys(keys)
+        else:
+            cand_dist, cand_rows = local
         combined, perm = e.fuse_sort(cand_dist, counts, q_term_offs, n, boost)
         return {"cand_dist": cand_dist, "cand_rows": cand_rows, "cand_counts": counts, "combined": combined, "perm": perm}
 
@@ -170,9 +173,9 @@ class HybridPipeline:
     A batch is a chain of kernels with very different appetites: the matrix-core scan fills the MFMA
     pipes, the candidate sort / gather / exact re-score that follows is bound by the latency of
     scattered row reads.  The scans take turns (hrs_ctx_set_peer); `submit` begins batch i + 1 on the
-    next stream and only then enqueues the tail of batch i, which the library holds back until batch
-    i + 1 has its thresholds: the tail then runs under the next main pass (both fit a CU's LDS and
-    registers together) instead of beside the sampled passes that precede it.  On a row-sharded corpus the
+    next stream and only then enqueues the tail of batch i, which runs right behind its own main pass, beside
+    the sampled passes of batch i + 1 (the two share the chip at workgroup granularity; queued under the next
+    main pass instead, the tail only ran when that pass retired).  On a row-sharded corpus the
     exchange step of batch i (all-gather, merge, fusion) goes to a third stream of its own, so it too is in
     flight under the scan of batch i + 1.  Every batch runs every kernel of ShardedHybrid.step and results
     are identical.
