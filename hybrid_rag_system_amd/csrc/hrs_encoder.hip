@@ -274,11 +274,32 @@ __global__ __launch_bounds__(512) void k_gemm(GemmArgs a) {
 // depth = 96 VGPRs) and streams 64-token activation tiles through a 3-deep LDS ring (LDS-DMA, two
 // tiles in flight, one barrier per tile) -- the scan kernel's structure with an output epilogue.
 // No weight byte is ever re-read; activations are read once per 384-feature group.
+#ifdef HRS_ENC_PROF
+// in-kernel phase clocks of the FFN up projection (10 ns units, summed over waves): see tools/enc_phases.py
+static __device__ unsigned long long g_enc_prof[8];
+extern "C" int hrs_encoder_prof_dump() {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_enc_prof), sizeof(h)) != hipSuccess) return -1;
+    const double w = (double)h[7] > 0 ? (double)h[7] : 1.0;  // waves
+    fprintf(stderr, "gemm_ws<GELU> per wave (us): total %.1f | wait+barrier %.1f | mfma phase %.1f | epilogue %.1f | tiles/wave %.1f\n",
+            h[0] / w / 100.0, h[1] / w / 100.0, h[2] / w / 100.0, h[3] / w / 100.0, h[4] / w);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_enc_prof), z, sizeof(z));
+    return 0;
+}
+#endif
+
 struct GemmWsArgs {
     const __bf16* A;     // [M, 384]
     const __bf16* W;     // [N, 384]
     const float* bias;   // [N]
-    __bf16* C;           // [M, N] (EPI_GELU)
+    __bf16* C;           // [M, N] (EPI_GELU); fragment-major when frag_out is set (see there)
+    // EPI_GELU: the output leaves in the order in which the next GEMM's MFMAs take it as an operand -- per 32 tokens
+    // and 16 features one 1 KB block of 64 lanes x 16 bytes (lane (token i, half h): features 8h .. 8h+7), blocks
+    // [M / 32][N / 16].  A store instruction of a wave then writes 1 KB of consecutive bytes instead of 32 bytes into
+    // each of 32 rows (a third of this kernel's time went into the 25 M 32-byte write requests of the row-major form),
+    // the consumer's LDS-DMA copies consecutive bytes and its fragment reads are lane-linear.
+    int frag_out;
     __bf16* q;
     __bf16* k;
     __bf16* vf;
@@ -407,7 +428,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
                 float v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
                 float v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
+#ifdef HRS_ENC_NOGELU
+                if (false) {
+#else
                 if (EPI == EPI_GELU) {
+#endif
                     f32x2 g01, g23;
                     g01.x = v0;
                     g01.y = v1;
@@ -438,15 +463,34 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             } else {
                 dst = a.C + (size_t)token * a.N + wfeat;
             }
-            *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
-            *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
+#ifdef HRS_ENC_NOSTORE
+            const u32x4 e0 = piece_exchange(o[0], o[1]), e1 = piece_exchange(o[2], o[3]);
+            if (e0.x == 0x12345678u && e1.y == 0x9abcdef0u) *(u32x4*)(dst + 8 * h) = e0;  // (never)
+#else
+            if (EPI == EPI_GELU && a.frag_out) {
+                // this wave's features are two 16-feature k-steps of the consumer: two consecutive 1 KB blocks
+                __bf16* fb = a.C + (((size_t)(tok0 >> 5) * (a.N >> 4) + (wfeat >> 4)) * 64 + lane) * 8;
+                *(u32x4*)fb = piece_exchange(o[0], o[1]);
+                *(u32x4*)(fb + 512) = piece_exchange(o[2], o[3]);
+            } else {
+                *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
+                *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
+            }
+#endif
         }
     };
 
+#ifdef HRS_ENC_PROF
+    const long long pk0 = wall_clock64();
+    long long p_wait = 0, p_mfma = 0, p_epi = 0;
+#endif
     issue(0, 0);
     issue(1, 1);
     int buf = 0;
     for (int n = 0; n < count; ++n) {
+#ifdef HRS_ENC_PROF
+        const long long pw0 = wall_clock64();
+#endif
         // outstanding, oldest first: DMA(n), DMA(n+1), then the NST stores of tile n-1 (none before the first tile)
         // (EPI_LN: two subtiles of 4 stores and DMA(n+1) between them: its DMA is issued in the middle of the tile)
         if (n == 0)
@@ -454,6 +498,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
         else
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef HRS_ENC_PROF
+        p_wait += wall_clock64() - pw0;
+#endif
         int nb = buf + 2;
         if (nb >= 3) nb -= 3;
         if (EPI != EPI_LN) issue(n + 2, nb);
@@ -475,6 +522,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
         for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(rowoff + buf * TILE_BYTES + (((2 * c) ^ vx) << 4));
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
+#ifdef HRS_ENC_PROF
+            const long long pm0 = wall_clock64();
+#endif
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -506,6 +556,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
 
+#ifdef HRS_ENC_PROF
+            asm volatile("s_nop 0" : "+v"(acc));  // the clock is read when the last result exists
+            const long long pm1 = wall_clock64();
+            p_mfma += pm1 - pm0;
+#endif
             const int tok0 = (t_begin + n) * TR + sb * 32;
             if (EPI == EPI_LN) {
                 const int token = tok0 + i;
@@ -568,10 +623,23 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             } else {
                 epilogue(acc, tok0);
             }
+#ifdef HRS_ENC_PROF
+            p_epi += wall_clock64() - pm1;
+#endif
         }
         buf = buf + 1 == 3 ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef HRS_ENC_PROF
+    if (EPI == EPI_GELU && lane == 0) {
+        atomicAdd(&g_enc_prof[0], (unsigned long long)(wall_clock64() - pk0));
+        atomicAdd(&g_enc_prof[1], (unsigned long long)p_wait);
+        atomicAdd(&g_enc_prof[2], (unsigned long long)p_mfma);
+        atomicAdd(&g_enc_prof[3], (unsigned long long)p_epi);
+        atomicAdd(&g_enc_prof[4], (unsigned long long)count);
+        atomicAdd(&g_enc_prof[7], 1ull);
+    }
+#endif
 }
 
 template <int EPI>
@@ -593,7 +661,7 @@ __global__ __launch_bounds__(768) void k_gemm_ws(GemmWsArgs a) {
 // 32-token x 512-deep stages (32 KB) through a 4-deep LDS ring by LDS-DMA, three stages in flight;
 // a token tile is finished every third stage.  Output: bias added, bf16, token-major.
 struct GemmDownArgs {
-    const __bf16* A;    // [M, 1536]
+    const __bf16* A;    // fragment-major [M / 32][96][64 lanes][8]: GemmWsArgs::frag_out
     const __bf16* W;    // [384, 1536]
     const float* bias;  // [384]
     __bf16* C;          // [M, 384]
@@ -646,23 +714,20 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
         int srcoff[IPW];
 #pragma unroll
         for (int ii = 0; ii < IPW; ++ii) {
-            const int g = (wv * IPW + ii) * 64 + lane;  // 16-byte piece of the stage: 64 per row
-            const int r = g >> 6, p = g & 63;
-            srcoff[ii] = r * (K * 2) + ((p ^ (r & 15)) << 4);
+            srcoff[ii] = ((wv * IPW + ii) * 64 + lane) * 16;  // a stage is 32 consecutive 1 KB operand fragments
         }
         const uint32_t lds0 = lds_addr_of(smem);
         auto issue = [&](int g) {
             if (g >= stages) g = stages - 1;
             const int t = t_begin + g / SPT, kc = g % SPT;
-            const char* base = uniform_ptr((const char*)a.A + ((size_t)t * 32 * K + kc * KC) * 2);
+            const char* base = uniform_ptr((const char*)a.A + ((size_t)t * (K / 16) + kc * KSS) * 1024);
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(g % NBUF) * STAGE + wv * (IPW * 1024));
 #pragma unroll
             for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
         };
         typedef const __attribute__((address_space(3))) char* lds_cptr;
         typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
-        const int rowoff = (int)lds0 + i * ROWB;
-        const int vx = h ^ (i & 15);
+        const int fragoff = (int)lds0 + lane * 16;  // fragment s of a stage: + s * 1024, lane-linear
 
         issue(0);
         issue(1);
@@ -679,9 +744,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
             __builtin_amdgcn_s_barrier();
             issue(g + 3);
             stored = false;
-            lds_cptr tb[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(rowoff + (g % NBUF) * STAGE + (((2 * c) ^ vx) << 4));
+            const lds_cptr tb = (lds_cptr)(size_t)(uint32_t)(fragoff + (g % NBUF) * STAGE);
             if (kc == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -691,10 +754,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
                 constexpr int KCI = decltype(kc_tag)::value;
                 bf16x8 av[KSS];
 #pragma unroll
-                for (int s = 0; s < PF; ++s) av[s] = *(lds_frag)(tb[s & 7] + (s >> 3) * 256);
+                for (int s = 0; s < PF; ++s) av[s] = *(lds_frag)(tb + s * 1024);
 #pragma unroll
                 for (int s = 0; s < KSS; ++s) {
-                    if (s + PF < KSS) av[s + PF] = *(lds_frag)(tb[(s + PF) & 7] + ((s + PF) >> 3) * 256);
+                    if (s + PF < KSS) av[s + PF] = *(lds_frag)(tb + (s + PF) * 1024);
                     if (KCI * KSS + s < NA)
                         mfma_wa(acc, wf[KCI * KSS + s], av[s]);  // D[feature][token]
                     else
@@ -1232,6 +1295,7 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         gw.bias = L.bi;
         gw.C = hbuf;
         gw.N = I;
+        gw.frag_out = I == 1536;  // k_gemm_down takes the hidden activations in its own operand order
         if ((rc = launch_gemm_ws<EPI_GELU>(ctx, gw, st))) return rc;
         if (I == 1536) {
             GemmDownArgs gd;
