@@ -281,8 +281,8 @@ extern "C" int hrs_encoder_prof_dump() {
     unsigned long long h[8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_enc_prof), sizeof(h)) != hipSuccess) return -1;
     const double w = (double)h[7] > 0 ? (double)h[7] : 1.0;  // waves
-    fprintf(stderr, "gemm_ws<GELU> per wave (us): total %.1f | wait+barrier %.1f | mfma phase %.1f | epilogue %.1f | tiles/wave %.1f\n",
-            h[0] / w / 100.0, h[1] / w / 100.0, h[2] / w / 100.0, h[3] / w / 100.0, h[4] / w);
+    fprintf(stderr, "gemm_ws<GELU> per wave (us): total %.1f | wait+barrier %.1f | mfma phase %.1f | epilogue %.1f (of which the two stores %.1f) | tiles/wave %.1f\n",
+            h[0] / w / 100.0, h[1] / w / 100.0, h[2] / w / 100.0, h[3] / w / 100.0, h[5] / w / 100.0, h[4] / w);
     unsigned long long z[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_enc_prof), z, sizeof(z));
     return 0;
@@ -405,6 +405,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     const int rowoff = (int)lds0 + i * RB;
     const int vx = h ^ (i & 15);
 
+#ifdef HRS_ENC_PROF
+    long long p_store = 0;
+#endif
     // epilogue of one 32-token subtile for the outputs without LayerNorm: 4 stores per lane
     auto epilogue = [&](const f32x16& acc, const int tok0) __attribute__((always_inline)) {
         if (vwave) {
@@ -465,13 +468,24 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             }
 #ifdef HRS_ENC_NOSTORE
             const u32x4 e0 = piece_exchange(o[0], o[1]), e1 = piece_exchange(o[2], o[3]);
-            if (e0.x == 0x12345678u && e1.y == 0x9abcdef0u) *(u32x4*)(dst + 8 * h) = e0;  // (never)
+            // (never taken, but every value stays live: an ablation must not let the compiler drop the arithmetic)
+            if ((e0.x ^ e0.y ^ e0.z ^ e0.w ^ e1.x ^ e1.y ^ e1.z ^ e1.w) == 0x12345678u) *(u32x4*)(dst + 8 * h) = e0;
 #else
             if (EPI == EPI_GELU && a.frag_out) {
                 // this wave's features are two 16-feature k-steps of the consumer: two consecutive 1 KB blocks
                 __bf16* fb = a.C + (((size_t)(tok0 >> 5) * (a.N >> 4) + (wfeat >> 4)) * 64 + lane) * 8;
+#ifdef HRS_ENC_PROF
+                u32x4 e0 = piece_exchange(o[0], o[1]), e1 = piece_exchange(o[2], o[3]);
+                asm volatile("" : "+v"(e0), "+v"(e1));
+                const long long ps0 = wall_clock64();
+                *(u32x4*)fb = e0;
+                *(u32x4*)(fb + 512) = e1;
+                asm volatile("" ::: "memory");
+                p_store += wall_clock64() - ps0;
+#else
                 *(u32x4*)fb = piece_exchange(o[0], o[1]);
                 *(u32x4*)(fb + 512) = piece_exchange(o[2], o[3]);
+#endif
             } else {
                 *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
                 *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
@@ -483,6 +497,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
 #ifdef HRS_ENC_PROF
     const long long pk0 = wall_clock64();
     long long p_wait = 0, p_mfma = 0, p_epi = 0;
+    p_store = 0;
 #endif
     issue(0, 0);
     issue(1, 1);
@@ -637,6 +652,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
         atomicAdd(&g_enc_prof[2], (unsigned long long)p_mfma);
         atomicAdd(&g_enc_prof[3], (unsigned long long)p_epi);
         atomicAdd(&g_enc_prof[4], (unsigned long long)count);
+        atomicAdd(&g_enc_prof[5], (unsigned long long)p_store);
         atomicAdd(&g_enc_prof[7], 1ull);
     }
 #endif
