@@ -73,6 +73,32 @@ def chunk_text(text, chunk_size, overlap):
     return pieces
 
 
+_SECTION_HEADING = re.compile(r'(^##?\s+.+$)', re.MULTILINE)
+
+
+def chunk_document(content, chunk_size=2000, overlap=200):
+    """The multi-system indexer's chunker (reference scripts/index-all-systems.py:355-387; defaults from its
+    RAG_CHUNK_SIZE / RAG_CHUNK_OVERLAP, :39-40).  The text is cut before every level-1/2 markdown heading; pieces are
+    packed greedily into chunks of at most chunk_size characters (a piece that does not fit starts a new chunk, which
+    begins with the last `overlap` characters of the one just closed); chunks are stripped.  If that yields nothing,
+    or a chunk longer than 1.5 x chunk_size (a section without headings), the text is cut into plain windows of
+    chunk_size characters every chunk_size - overlap instead (blank windows dropped).  Never returns an empty list."""
+    pieces = _SECTION_HEADING.split(content)
+    chunks, cur = [], ""
+    for piece in pieces:
+        if cur and len(cur) + len(piece) > chunk_size:
+            chunks.append(cur.strip())
+            cur = (cur[-overlap:] if overlap > 0 else "") + piece
+        else:
+            cur += piece
+    if cur.strip():
+        chunks.append(cur.strip())
+    if not chunks or max(len(c) for c in chunks) > chunk_size * 1.5:
+        step = chunk_size - overlap
+        chunks = [w.strip() for w in (content[i:i + chunk_size] for i in range(0, len(content), step)) if w.strip()]
+    return chunks if chunks else [content]
+
+
 def generate_doc_id(content, source=""):
     """chromadb_helper.py:223-226."""
     return hashlib.sha256((source + ":" + content[:500]).encode()).hexdigest()[:16]

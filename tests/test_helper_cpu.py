@@ -222,3 +222,23 @@ def test_where_forms_of_the_reference_callers():
     assert _match({}, {"system": {"$ne": "x"}}) and not _match({}, {"system": {"$eq": "x"}})
     with pytest.raises(ValueError, match="unsupported where operator"):
         _match(m, {"system": {"$regex": "u.*"}})
+
+
+def test_chunk_document_matches_the_reference():
+    """The multi-system indexer's chunker against chunks produced by the reference's own function
+    (tests/golden/make_chunk_document_goldens.py): count, lengths and hashes of every chunk."""
+    import hashlib
+    import json
+    import os
+
+    from hybrid_rag_system_amd.textproc import chunk_document
+    from tests.chunk_document_cases import build_cases
+
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chunk_document_goldens.json")))
+    cases = build_cases()
+    assert set(cases) == set(want) and len(cases) >= 30
+    for name, (text, kw) in cases.items():
+        got = chunk_document(text, **kw)
+        assert len(got) == want[name]["n"], name
+        assert [len(c) for c in got] == want[name]["lens"], name
+        assert [hashlib.sha256(c.encode()).hexdigest()[:16] for c in got] == want[name]["sha"], name
