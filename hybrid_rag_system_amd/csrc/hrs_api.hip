@@ -383,7 +383,11 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     }
 #endif
 #ifdef HRS_SEL_PROF
-    fprintf(stderr, "select: init %lld resc %lld total %lld (x10 ns, summed over queries) rounds %lld maxcand %lld\n", (long long)h[4], (long long)h[5], (long long)h[6], (long long)h[7], (long long)h[1]);
+    {
+        int64_t g[16];
+        HRS_CHECK_HIP(hipMemcpy(g, ctx->stats_dev, sizeof(g), hipMemcpyDeviceToHost));
+        fprintf(stderr, "select: init %lld resc %lld total %lld (x10 ns, summed over queries) rounds %lld maxcand %lld\n", (long long)g[12], (long long)g[13], (long long)g[14], (long long)g[15], (long long)h[1]);
+    }
 #endif
     return HRS_OK;
 }

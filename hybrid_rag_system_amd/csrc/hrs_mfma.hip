@@ -1343,10 +1343,10 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
     }
 #ifdef HRS_SEL_PROF
     if (tid == 0) {
-        atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)pt_init);
-        atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)pt_resc);
-        atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)(wall_clock64() - pt0));
-        atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)pt_rounds);
+        atomicAdd((unsigned long long*)&a.stats[12], (unsigned long long)pt_init);
+        atomicAdd((unsigned long long*)&a.stats[13], (unsigned long long)pt_resc);
+        atomicAdd((unsigned long long*)&a.stats[14], (unsigned long long)(wall_clock64() - pt0));
+        atomicAdd((unsigned long long*)&a.stats[15], (unsigned long long)pt_rounds);
     }
 #endif
     if (tid == 0) {
@@ -1587,7 +1587,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     (void)hipMemsetAsync(ctx->stats_dev + 8, 0xFF, 8, st);                     \
     (void)hipMemsetAsync(ctx->stats_dev + 9, 0, 8, st);                        \
     (void)hipMemsetAsync(ctx->stats_dev + 10, 0xFF, 8, st);                    \
-    (void)hipMemsetAsync(ctx->stats_dev + 11, 0, 8, st);
+    (void)hipMemsetAsync(ctx->stats_dev + 11, 0, 8, st);                       \
+    (void)hipMemsetAsync(ctx->stats_dev + 12, 0, 32, st);
 #else
 #define HRS_SCAN_PROF_RESET
 #endif
