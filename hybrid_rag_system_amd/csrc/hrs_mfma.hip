@@ -110,6 +110,7 @@ struct MfmaArgs {
     uint64_t* cand;        // [Bpad][HRS_CAND_CAP_BIG]
 #ifdef HRS_SCAN_PROF
     long long* prof;
+    float prof_tau_shift;  // HRS_PROF_TAU_SHIFT: added to the main pass's thresholds (a large value: a pass without hits)
 #endif
 };
 
@@ -135,6 +136,9 @@ __device__ __forceinline__ float raised_tau(const MfmaArgs& a, int q) {
     }
     if (step > 15) step = 15;
     if (li > 0.f && step > 0) t += (float)step / li;
+#ifdef HRS_SCAN_PROF
+    t += a.prof_tau_shift;
+#endif
     return t;
 }
 
@@ -1546,6 +1550,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.tau_out = (float*)(ws + o_tau2);
 #ifdef HRS_SCAN_PROF
         a.prof = (long long*)ctx->stats_dev;
+        a.prof_tau_shift = getenv("HRS_PROF_TAU_SHIFT") ? (float)atof(getenv("HRS_PROF_TAU_SHIFT")) : 0.f;
 #endif
         a.raise_limit = HRS_CAND_CAP_BIG / 4;
         a.cnt = (int*)(ws + o_cnt);
