@@ -3,9 +3,9 @@
 
 #include "hrs_internal.h"
 
-// One wave per (query, candidate): the 64 lanes read the row's term list coalesced and compare each
-// term with the query's terms (wave-uniform, read through the scalar path); a ballot per query term
-// gives its presence.  Integer work only.
+// One wave per (query, candidate): the 64 lanes read the row's term list coalesced, 64 terms at a time, and every
+// query term (wave-uniform, at most 64 per round) is compared with all of them at once: one compare and one ballot
+// per query term and block, the terms found collected as bits of a scalar mask.  Integer work only.
 __global__ __launch_bounds__(256) void k_keyword_counts(const int64_t* __restrict__ doc_offs,
                                                         const int32_t* __restrict__ term_ids, int64_t N,
                                                         int64_t row_offset, const int32_t* __restrict__ q_terms,
@@ -22,21 +22,17 @@ __global__ __launch_bounds__(256) void k_keyword_counts(const int64_t* __restric
         const int64_t p0 = doc_offs[row], p1 = doc_offs[row + 1];
         const int t0 = q_term_offs[b], t1 = q_term_offs[b + 1];
         for (int tb = t0; tb < t1; tb += 64) {
-            // lanes hold up to 64 query terms; presence bit per lane
             const int nt = min(64, t1 - tb);
-            const int my = lane < nt ? q_terms[tb + lane] : -1;
-            bool found = false;
+            const int my = lane < nt ? q_terms[tb + lane] : -1;  // this round's query terms, one per lane
+            uint64_t found = 0;                                    // bit j: query term tb + j occurs in the row
             for (int64_t p = p0; p < p1; p += 64) {
-                const int m = (int)min((int64_t)64, p1 - p);
-                const int dt = lane < m ? term_ids[p + lane] : -2;
-                // every lane checks its query term against the 64 document terms of this block
-                for (int j = 0; j < m; ++j) {
-                    int v = __shfl(dt, j);
-                    found |= (v == my);
+                const int dt = p + lane < p1 ? term_ids[p + lane] : -2;
+                for (int j = 0; j < nt; ++j) {
+                    const int qt = __builtin_amdgcn_readlane(my, j);
+                    if (__builtin_amdgcn_ballot_w64(dt == qt) != 0) found |= 1ull << j;
                 }
             }
-            unsigned long long bal = __ballot(found && lane < nt);
-            n += __popcll(bal);
+            n += __builtin_popcountll(found);
         }
     }
     if (lane == 0) counts[pair] = n;
