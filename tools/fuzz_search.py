@@ -51,8 +51,12 @@ def run(eng, seed, cases, verbose=True, large=False):
               c.append(dC, cut)
           for mode in ("mfma", "exact", "auto"):
               if mode == "exact" and shadow == "bf16": continue
-              _, _, keys = eng.score_topk(c, dQ, k, space=space, mask=dm, mode=mode, want_keys=True)
+              dist, rows, keys = eng.score_topk(c, dQ, k, space=space, mask=dm, mode=mode, want_keys=True)
               torch.cuda.synchronize()
+              wd, wr = so.unpack(want)  # the unpacked outputs come from the kernels that write the final keys
+              if not (np.array_equal(rows.cpu().numpy(), wr) and np.array_equal(dist.cpu().numpy().view(np.uint32), wd.view(np.uint32))):
+                  bad += 1
+                  print(f"MISMATCH (unpacked) it={it} n={n} d={d} b={b} k={k} {space} kind={kind} mask={use_mask} {shadow} {mode}", flush=True)
               if not np.array_equal(keys.cpu().numpy().view(np.uint64), want):
                   bad += 1
                   print(f"MISMATCH it={it} n={n} d={d} b={b} k={k} {space} kind={kind} mask={use_mask} {shadow} {mode} {eng.score_stats()}", flush=True)
