@@ -217,34 +217,36 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                     }
                 };
                 if (SQ && pieces == EDC / 4) {
-                    // Full segment, queries through the scalar cache.  The compiler would request all 256 scalar
-                    // registers' worth of a segment at once and park them in vector lanes; here two pieces of four
-                    // values per query are live: piece s + 1 is requested before piece s is used.  Scalar loads return
-                    // in any order, so the only wait is lgkmcnt(0) -- hence the row itself is read from LDS up front.
-                    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+                    // Full segment, queries through the scalar cache.  Left alone, the compiler requests all 256 scalar
+                    // registers' worth of a segment at once and parks them in vector lanes; here two pieces of four
+                    // values per query are live: piece s + 1 is requested behind the point where piece s is known to
+                    // have arrived and before it is used.  Scalar loads return in any order, so the compiler's wait for
+                    // them is lgkmcnt(0) -- hence the row itself is read from LDS up front.  The loads are ordinary
+                    // loads through the constant address space (hand-written s_load statements are not safe: the
+                    // compiler may copy their destination registers before a hand-written wait); the empty asm that
+                    // takes piece s as an input is what places the compiler's wait.
+                    typedef double f64x4 __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(4))) f64x4* qd4_ptr;
                     float4 cv[EDC / 4];
 #pragma unroll
                     for (int s = 0; s < EDC / 4; ++s) cv[s] = *(const float4*)(rowp + ((s ^ sw) << 4));
-                    u32x8 qv[2][NQT];
-                    auto request = [&](int s) __attribute__((always_inline)) {
+                    f64x4 nxt[NQT];
 #pragma unroll
-                        for (int b = 0; b < NQT; ++b)
-                            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(qv[s & 1][b]) : "s"(qrow[b] + ch * EDC + s * 4));
-                    };
-                    auto arrived = [&](int s) __attribute__((always_inline)) {
-                        if (NQT == 4)
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qv[s & 1][0]), "+s"(qv[s & 1][1]), "+s"(qv[s & 1][2]), "+s"(qv[s & 1][3]));
-                        else
-#pragma unroll
-                            for (int b = 0; b < NQT; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qv[s & 1][b]));
-                    };
-                    request(0);
-#pragma unroll
-                    for (int s = 0; s < EDC / 4; ++s) asm volatile("" : "+v"(cv[s].x), "+v"(cv[s].y), "+v"(cv[s].z), "+v"(cv[s].w));
-                    arrived(0);
+                    for (int b = 0; b < NQT; ++b) nxt[b] = *(qd4_ptr)(qrow[b] + ch * EDC);
 #pragma unroll
                     for (int s = 0; s < EDC / 4; ++s) {
-                        if (s + 1 < EDC / 4) request(s + 1);
+                        f64x4 cur[NQT];
+#pragma unroll
+                        for (int b = 0; b < NQT; ++b) {
+                            cur[b] = nxt[b];
+                            asm volatile("" ::"s"(cur[b]));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s + 1 < EDC / 4) {
+#pragma unroll
+                            for (int b = 0; b < NQT; ++b) nxt[b] = *(qd4_ptr)(qrow[b] + ch * EDC + (s + 1) * 4);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                         const double c0 = (double)cv[s].x, c1 = (double)cv[s].y, c2 = (double)cv[s].z, c3 = (double)cv[s].w;
                         if (SPACE == HRS_SPACE_COSINE) {
                             ncacc = fma(c0, c0, ncacc);
@@ -254,11 +256,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                         }
 #pragma unroll
                         for (int b = 0; b < NQT; ++b) {
-                            const u32x8 w = qv[s & 1][b];
-                            const double q0 = __builtin_bit_cast(double, ((uint64_t)w[1] << 32) | w[0]);
-                            const double q1 = __builtin_bit_cast(double, ((uint64_t)w[3] << 32) | w[2]);
-                            const double q2 = __builtin_bit_cast(double, ((uint64_t)w[5] << 32) | w[4]);
-                            const double q3 = __builtin_bit_cast(double, ((uint64_t)w[7] << 32) | w[6]);
+                            const double q0 = cur[b][0], q1 = cur[b][1], q2 = cur[b][2], q3 = cur[b][3];
                             if (SPACE == HRS_SPACE_L2) {
                                 const double d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
                                 acc[b] = fma(d0, d0, acc[b]);
@@ -272,7 +270,6 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                                 acc[b] = fma(q3, c3, acc[b]);
                             }
                         }
-                        if (s + 1 < EDC / 4) arrived(s + 1);
                     }
                 } else if (pieces == EDC / 4) {
                     // full segment: unrolled, so the LDS reads of all 16 pieces are in flight together

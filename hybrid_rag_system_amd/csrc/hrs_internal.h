@@ -93,8 +93,8 @@ struct hrs_corpus {
     int want_kind = HRS_SHADOW_AUTO;  // what the caller asked for (an empty corpus has no shadow yet)
     int64_t cap = 0;           // rows the shadow allocation holds (>= Npad); grows geometrically on append
     void* shadow = nullptr;    // owned: bf16 or int8 [Npad, Dpad], zero padded
-    float2* group_pre = nullptr;   // owned (int8 shadow): per 32-row group (scale, M_g); then, in the same
-    float2* group_main = nullptr;  // allocation, (1 / scale, M_g)
+    float4* group_pre = nullptr;   // owned (int8 shadow): per 32-row group (scale, E_g, C_g + E_g, -); then, in the same
+    float4* group_main = nullptr;  // allocation, (1 / scale, E_g, C_g + E_g, -)
     int64_t Npad = 0;
     int Dpad = 0;
     double* norm_stats = nullptr;  // owned: {min |c|^2, max |c|^2} as doubles

@@ -30,15 +30,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // The scan runs on one of two shadows of the corpus.  bf16: v_mfma_f32_32x32x16_bf16, 16 depth
 // elements per k-step.  int8: v_mfma_i32_32x32x32_i8, 32 depth elements per k-step, twice the rate and
-// half the bytes; each 32-row group g carries one fp32 scale s_g (row value = s_g * int8), queries one
-// scale each.  With e = I8_EMAX, q = sq (qi + eq), c = s_g (ci + ec), |eq|, |ec| <= e:
-//     q.c / sq  <=  s_g * (qi.ci + K_q + M_g),   K_q = e |qi|_1 + e^2 D,   M_g = e max_rows |ci|_1
-// and the int8 kernel filters, records and ranks by that UPPER BOUND of the scaled score, so a row it
-// does not record is provably below the threshold and no further error term enters the acceptance test.
+// half the bytes; each 32-row group g carries one fp32 scale s_g (row value = s_g * (int8 + error)), queries one
+// scale each.  With q = sq (qi + eq), c = s_g (ci + ec) -- eq, ec the quantisation residuals, known when the
+// vectors are quantised -- and the Cauchy-Schwarz inequality on the three cross terms:
+//     q.c / sq  <=  s_g * (qi.ci + |qi| E_g + |eq| (C_g + E_g)),   E_g = max_rows |ec|,  C_g = max_rows |ci|
+// (Euclidean norms, rounded up) and the int8 kernel filters, records and ranks by that UPPER BOUND of the scaled
+// score, so a row it does not record is provably below the threshold and no further error term enters the
+// acceptance test.  (The bound from the residuals' maximum, e |qi|_1 + e |ci|_1 + e^2 D with e = 0.5, is 1.4 x
+// looser: 0.48 instead of 0.35 standard deviations of the scores of random unit rows at depth 384, 0.74 instead of
+// 0.54 at depth 1024, where it made the int8 shadow useless -- thirty recorded rows for one above the threshold.)
 // Either way a fragment is 16 bytes per lane and a row is KS * 32 bytes, so the addressing is shared.
 template <bool I8> struct scan_types { typedef bf16x8 frag; typedef f32x16 acc; };
 template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
-#define I8_EMAX 0.5001   // bound of |x / scale - rint(x / scale)| incl. the fp32 division error
 
 #ifndef HRS_SCAN_PF
 #define HRS_SCAN_PF 4
@@ -90,8 +93,8 @@ __device__ __forceinline__ size_t qfrag_offset(int q, int kstep, int half, int k
 struct MfmaArgs {
     const char* shadow;    // [Npad][KS * 32 bytes]
     const char* qb;        // [Bpad / 32][KS][2][32][16 bytes], see qfrag_offset
-    const float2* group;   // int8 only, per 32-row group: (s_g, M_g) for PRE, (1 / s_g, M_g) for MAIN
-    const float* kq;       // int8 only, per query: K_q
+    const float4* group;   // int8 only, per 32-row group: (s_g, E_g, C_g + E_g, -) for PRE, (1 / s_g, ...) for MAIN
+    const float2* kq;      // int8 only, per query: (|qi|, |eq|)
     int64_t N;
     int64_t tiles;         // ceil(N / TR)
     int64_t row_offset;
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     // The queries of this wave: fragments, thresholds and error terms.  Requested right behind the first corpus tile
     // (the requests are independent, and a pass over a small corpus is short enough for a serial start to show).
     frag_t qf[QT][KS];
-    float tau[QT], kq[QT], linv[QT];
+    float tau[QT], linv[QT];
+    float2 kq[QT];  // int8: (|qi|, |eq|) of the lane's query
     float mx[QT][WSUB];
     auto load_queries = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         for (int qt = 0; qt < QT; ++qt) {
             tau[qt] = MAXIMA ? 0.f : (LADDER ? a.tau[q0 + qt * 32 + i] : raised_tau(a, q0 + qt * 32 + i));
             if (MODE == 0 && slice == 0 && sb0 == 0 && h == 0) a.tau_out[q0 + qt * 32 + i] = tau[qt];  // one writer per query
-            kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : 0.f;
+            kq[qt] = I8 ? a.kq[q0 + qt * 32 + i] : make_float2(0.f, 0.f);
             linv[qt] = LADDER ? a.lad_inv[q0 + qt * 32 + i] : 0.f;
 #pragma unroll
             for (int sb = 0; sb < WSUB; ++sb) mx[qt][sb] = -__builtin_inff();
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt]), "+v"(linv[qt]));
+        for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt].x), "+v"(kq[qt].y), "+v"(linv[qt]));
         if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
     };
 
@@ -302,24 +306,25 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         typedef const __attribute__((address_space(3))) char* lds_cptr;
         typedef const __attribute__((address_space(3))) frag_t* lds_frag;
         constexpr int PF = HRS_SCAN_PF < KS ? HRS_SCAN_PF : KS;  // A fragments in flight
-        // int8: the group terms of a tile come by scalar load (its counter is lgkmcnt, so the LDS-DMA
-        // ring is left alone), requested one tile ahead
-        float2 sc[NSUB], scn[NSUB];
-        auto scale_load = [&](int64_t tile) __attribute__((always_inline)) {
+        // int8: the group terms of a tile come by scalar load (its counter is lgkmcnt, so the LDS-DMA ring is left
+        // alone).  The load is a hand-written statement at the top of the tile and its wait a second one behind the
+        // tile's first block of MFMAs, where the wave has no LDS read outstanding and the terms have long arrived: a load
+        // that the compiler tracks makes it wait for lgkmcnt(0) at the next LDS read (scalar loads return out of order),
+        // i.e. for the latency of the scalar load once per tile, in the middle of the MFMA chain.  The compiler does
+        // not know that the destination registers are pending between the two statements: the registers are one
+        // variable that only the wait statement reads (tied), with no value carried around the loop, and a test
+        // reads the generated code for any other access in between.
+        typedef float f32xg __attribute__((ext_vector_type(4 * NSUB)));
+        auto terms_request = [&](int64_t tile, f32xg& dst) __attribute__((always_inline)) {
             const char* p = uniform_ptr(a.group + tile * NSUB);
-            if (NSUB == 2) {
-                float4 v;
-                asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p));
-                scn[0] = make_float2(v.x, v.y);
-                scn[NSUB - 1] = make_float2(v.z, v.w);
-            } else {
-                asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(scn[0]) : "s"(p));
-            }
+            if constexpr (NSUB == 2)
+                asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst) : "s"(p));
+            else
+                asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(dst) : "s"(p));
         };
 #ifdef HRS_SCAN_PROF
         pt1 = wall_clock64();
 #endif
-        if (I8) scale_load(tile_at(0));
         // first tile, queries, rest of the ring: requests come back in order, and behind the whole ring (120 KB per
         // CU, 30 MB over the chip) the queries would arrive 5 us later than behind one tile
         issue(0, 0);
@@ -360,17 +365,9 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (s / NB) * FSTEP);
         for (int64_t n = 0; n < count; ++n) {
             const int64_t tile = tile_at(n);
-            if (I8) {
-#pragma unroll
-                for (int sb = 0; sb < NSUB; ++sb) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(scn[sb].x), "+s"(scn[sb].y));
-                    sc[sb] = scn[sb];
-                }
-                scale_load(tile_at(n + 1));
-            }
-            float2 scw[WSUB];  // the group terms of the 32-row groups this wave scores
-#pragma unroll
-            for (int sb = 0; sb < WSUB; ++sb) scw[sb] = RS ? (sb0 ? sc[NSUB - 1] : sc[0]) : sc[sb];
+            f32xg terms;
+            if constexpr (I8) terms_request(tile, terms);
+            f32x4 scw[WSUB];  // the group terms of the 32-row groups this wave scores
 #pragma unroll
             for (int sb = 0; sb < WSUB; ++sb) {
                 acc_t acc[QT];
@@ -399,6 +396,24 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, QT * PF, 0);
+                if constexpr (I8) {
+                    if (sb == 0) {
+                        __builtin_amdgcn_sched_barrier(0);  // (the wait stays behind the block's last MFMA)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(terms)::"memory");
+                        if constexpr (NSUB == 2) {
+                            const f32x4 lo = __builtin_shufflevector(terms, terms, 0, 1, 2, 3);
+                            const f32x4 hi = __builtin_shufflevector(terms, terms, 4, 5, 6, 7);
+                            if constexpr (RS) {
+                                scw[0] = sb0 ? hi : lo;
+                            } else {
+                                scw[0] = lo;
+                                scw[WSUB - 1] = hi;
+                            }
+                        } else {
+                            scw[0] = terms;
+                        }
+                    }
+                }
                 if (sb + 1 < WSUB) {
 #pragma unroll
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
@@ -439,33 +454,34 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) m4[g] = max(max(acc[qt][4 * g], acc[qt][4 * g + 1]), max(acc[qt][4 * g + 2], acc[qt][4 * g + 3]));
                         const int m = max(max(m4[0], m4[1]), max(m4[2], m4[3]));
+                        // what the three cross terms of the quantisation residuals can add: |qi| E_g + |eq| (C_g + E_g)
+                        // (the norms are rounded up by more than these two roundings can take away)
+                        const float xb = fmaf(kq[qt].x, scw[sb].y, kq[qt].y * scw[sb].z);
                         if (MAXIMA) {
-                            mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + kq[qt] + scw[sb].y) * scw[sb].x);  // .x = s_g
+                            mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + xb) * scw[sb].x);  // .x = s_g
                         } else if (LADDER) {
-                            if (((float)m + kq[qt] + scw[sb].y) * scw[sb].x > tau[qt]) {
+                            if (((float)m + xb) * scw[sb].x > tau[qt]) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
-                                    const float v = ((float)acc[qt][r] + kq[qt] + scw[sb].y) * scw[sb].x;
-                                    if (v > tau[qt]) atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + min(15, (int)((v - tau[qt]) * linv[qt]))], 1);
+                                    const float v = ((float)acc[qt][r] + xb) * scw[sb].x;
+                                    if (v > tau[qt]) atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + max(0, min(15, (int)((v - tau[qt]) * linv[qt])))], 1);
                                 }
                             }
                         } else {
-                            // s_g (acc + K_q + M_g) > tau  <=>  acc > tau / s_g - K_q - M_g; the threshold is
+                            // s_g (acc + xb) > tau  <=>  acc > tau / s_g - xb; the threshold is
                             // pushed down by more than the rounding of these few operations, so that no
                             // qualifying row is dropped
-                            float tf = tau[qt] * scw[sb].x;  // .x = 1 / s_g
+                            float tf = fminf(tau[qt] * scw[sb].x, 2.1e9f);  // .x = 1 / s_g (never +inf below: no inf - inf)
                             tf -= fabsf(tf) * 3e-7f;
-                            tf = tf - kq[qt] - scw[sb].y - 0.5f;
-                            const int ti = (int)floorf(fminf(fmaxf(tf, -2.1e9f), 2.1e9f));
+                            tf = tf - xb - 0.5f;
+                            const int ti = (int)floorf(fmaxf(tf, -2.1e9f));
                             if (__builtin_amdgcn_ballot_w64(m > ti) != 0) {  // wave-uniform: some lane holds such a row
-                                // s_g again, from its reciprocal: no vector load may appear in this loop (its
-                                // wait would drain the DMA ring); the acceptance test allows for the rounding
-                                const float gs = 1.0f / scw[sb].x;
+                                const float gs = scw[sb].w;  // s_g itself (.x is its reciprocal)
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
                                     if (__builtin_amdgcn_ballot_w64(m4[g] > ti) == 0) continue;
 #pragma unroll
-                                    for (int r = 4 * g; r < 4 * g + 4; ++r) append(acc[qt][r] > ti, r, [&]() { return ((float)acc[qt][r] + kq[qt] + scw[sb].y) * gs; });
+                                    for (int r = 4 * g; r < 4 * g + 4; ++r) append(acc[qt][r] > ti, r, [&]() { return ((float)acc[qt][r] + xb) * gs; });
                                 }
                             }
                         }
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r)
                                     if (acc[qt][r] > tau[qt])
-                                        atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + min(15, (int)((acc[qt][r] - tau[qt]) * linv[qt]))], 1);
+                                        atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + max(0, min(15, (int)((acc[qt][r] - tau[qt]) * linv[qt])))], 1);
                             }
                         } else if (__builtin_amdgcn_ballot_w64(m > tau[qt]) != 0) {
 #pragma unroll
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_scan_wide(MfmaArgs a) {
                     if (m > tau) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            if (acc[r] > tau) atomicAdd(&a.hist[(q0 + i) * 16 + min(15, (int)((acc[r] - tau) * linv))], 1);
+                            if (acc[r] > tau) atomicAdd(&a.hist[(q0 + i) * 16 + max(0, min(15, (int)((acc[r] - tau) * linv)))], 1);
                     }
                 } else if (m > tau) {
                     const int64_t tile = tile_at(g / SPT);
@@ -735,16 +751,16 @@ __global__ __launch_bounds__(256) void k_build_shadow(const float* __restrict__ 
 // value = rint(c / s_g)) and the group's pairs (s_g, M_g), (1 / s_g, M_g).  One workgroup per group.
 // Also min/max squared row norm (stats[0..1], doubles).
 __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict__ C, int64_t N, int D, int Dpad,
-                                                         int8_t* __restrict__ out, float2* __restrict__ pre_pair,
-                                                         float2* __restrict__ main_pair,
+                                                         int8_t* __restrict__ out, float4* __restrict__ pre_terms,
+                                                         float4* __restrict__ main_terms,
                                                          unsigned long long* __restrict__ stats, int64_t g0) {
     __shared__ float red[4];
-    __shared__ int l1max;
+    __shared__ unsigned long long e2max, c2max;  // largest squared norm of a row's residuals / of its int8 values
     __shared__ unsigned long long nmin, nmax;  // squared norms as bit patterns (non-negative doubles order like them)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t g = g0 + blockIdx.x, r0 = g * 32;  // g0: first group (re)built
     if (threadIdx.x == 0) {
-        l1max = 0;
+        e2max = c2max = 0ull;
         nmin = ~0ull;
         nmax = 0ull;
     }
@@ -764,7 +780,7 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
     const float gs = gmax / 127.0f;
     for (int rr = wv; rr < 32; rr += 4) {
         const int64_t r = r0 + rr;
-        int l1 = 0;
+        double e2 = 0.0, c2 = 0.0;  // of this row: squared residuals (value / s_g - int8, in real arithmetic), squared int8
         double ss = 0.0;
         for (int c = lane * 4; c < Dpad; c += 256) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -776,20 +792,25 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
                 q1 = (int)rintf(v.y / gs);
                 q2 = (int)rintf(v.z / gs);
                 q3 = (int)rintf(v.w / gs);
+                const double r0d = (double)v.x / (double)gs - q0, r1d = (double)v.y / (double)gs - q1;
+                const double r2d = (double)v.z / (double)gs - q2, r3d = (double)v.w / (double)gs - q3;
+                e2 += r0d * r0d + r1d * r1d + r2d * r2d + r3d * r3d;
             }
-            l1 += abs(q0) + abs(q1) + abs(q2) + abs(q3);
+            c2 += (double)(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
             const uint32_t packed = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) |
                                     ((uint32_t)(q3 & 0xff) << 24);
             *(uint32_t*)(out + r * Dpad + c) = packed;
         }
         for (int o = 32; o > 0; o >>= 1) {
-            l1 += __shfl_xor(l1, o);
+            e2 += __shfl_xor(e2, o);
+            c2 += __shfl_xor(c2, o);
             ss += __shfl_xor(ss, o);
         }
         if (lane == 0 && r < N) {
             atomicMin(&nmin, (unsigned long long)__double_as_longlong(ss));
             atomicMax(&nmax, (unsigned long long)__double_as_longlong(ss));
-            atomicMax(&l1max, l1);
+            atomicMax(&e2max, (unsigned long long)__double_as_longlong(e2));
+            atomicMax(&c2max, (unsigned long long)__double_as_longlong(c2));
         }
     }
     __syncthreads();
@@ -798,10 +819,12 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
             atomicMin(&stats[0], nmin);
             atomicMax(&stats[1], nmax);
         }
-        const float mg = (float)I8_EMAX * (float)l1max * 1.000001f + 0.01f;  // rounded up
+        // the two norms, rounded up (fp64 square root, then a relative and an absolute margin far above the fp32 rounding)
+        const float eg = (float)(sqrt(__longlong_as_double((long long)e2max)) * 1.000002 + 1e-4);
+        const float cg = (float)(sqrt(__longlong_as_double((long long)c2max)) * 1.000002 + 1e-4);
         // an all-zero group scores exactly 0: a huge reciprocal keeps it out for any positive threshold
-        pre_pair[g] = make_float2(gs, mg);
-        main_pair[g] = make_float2(gs > 0.f ? 1.0f / gs : 1e30f, mg);
+        pre_terms[g] = make_float4(gs, eg, cg + eg, 0.f);
+        main_terms[g] = make_float4(gs > 0.f ? 1.0f / gs : 1e30f, eg, cg + eg, gs);
     }
 }
 
@@ -856,12 +879,12 @@ void hrs_free_shadow(hrs_corpus* c) {
 static int64_t shadow_npad(int64_t N) { return (N + 63) / 64 * 64 + 64; }  // one spare tile: clamped prefetches stay in bounds
 
 // Allocates shadow storage for `cap` rows (a multiple of 64) of the corpus' kind / Dpad.
-static int shadow_alloc(const hrs_corpus* c, int64_t cap, void** shadow, float2** group_pre) {
+static int shadow_alloc(const hrs_corpus* c, int64_t cap, void** shadow, float4** group_pre) {
     const size_t esz = c->kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
     *shadow = nullptr;
     *group_pre = nullptr;
     hipError_t e = hipMalloc(shadow, (size_t)cap * c->Dpad * esz);
-    if (e == hipSuccess && c->kind == HRS_SHADOW_I8) e = hipMalloc((void**)group_pre, (size_t)(2 * (cap / 32) + 64) * sizeof(float2));
+    if (e == hipSuccess && c->kind == HRS_SHADOW_I8) e = hipMalloc((void**)group_pre, (size_t)(2 * (cap / 32) + 64) * sizeof(float4));
     if (e != hipSuccess) {
         if (*shadow) (void)hipFree(*shadow);
         *shadow = nullptr;
@@ -891,7 +914,7 @@ int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st) {
     (void)ctx;
     hrs_free_shadow(c);
     c->want_kind = kind;
-    if (kind == HRS_SHADOW_AUTO) kind = c->D <= 512 ? HRS_SHADOW_I8 : HRS_SHADOW_BF16;
+    if (kind == HRS_SHADOW_AUTO) kind = c->D <= 1024 ? HRS_SHADOW_I8 : HRS_SHADOW_BF16;
     c->Npad = shadow_npad(c->N);
     if (c->N == 0) return HRS_OK;
     hipError_t e = hipMalloc((void**)&c->norm_stats, 2 * sizeof(double));
@@ -944,14 +967,14 @@ int hrs_append_shadow(hrs_ctx* ctx, hrs_corpus* c, const float* C, int64_t N_new
         int64_t cap = c->cap * 2;
         if (cap < c->Npad) cap = c->Npad;
         void* ns = nullptr;
-        float2* ng = nullptr;
+        float4* ng = nullptr;
         int rc = shadow_alloc(c, cap, &ns, &ng);
         if (rc) return rc;
         const size_t esz = c->kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
         HRS_CHECK_HIP(hipMemcpyAsync(ns, c->shadow, (size_t)r_from * c->Dpad * esz, hipMemcpyDeviceToDevice, st));
         if (ng) {
-            HRS_CHECK_HIP(hipMemcpyAsync(ng, c->group_pre, (size_t)(r_from / 32) * sizeof(float2), hipMemcpyDeviceToDevice, st));
-            HRS_CHECK_HIP(hipMemcpyAsync(ng + cap / 32 + 32, c->group_main, (size_t)(r_from / 32) * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            HRS_CHECK_HIP(hipMemcpyAsync(ng, c->group_pre, (size_t)(r_from / 32) * sizeof(float4), hipMemcpyDeviceToDevice, st));
+            HRS_CHECK_HIP(hipMemcpyAsync(ng + cap / 32 + 32, c->group_main, (size_t)(r_from / 32) * sizeof(float4), hipMemcpyDeviceToDevice, st));
         }
         HRS_CHECK_HIP(hipStreamSynchronize(st));  // the copies are done (and so is whatever read the old shadow on st)
         (void)hipFree(c->shadow);
@@ -978,10 +1001,11 @@ __device__ __forceinline__ void zero_words(const ZeroList& z) {
 }
 
 // Queries fp32 [B, D] -> int8 [Bpad, Dpad] with one scale per query (max |q| / 127); squared norms in
-// fp64, the scale and K_q = e |q_int|_1 + e^2 D of the error bound.  One wave per query.
+// fp64, the scale, and the two norms of the error bound: of the int8 values and of the residuals
+// (q / scale - int8, in real arithmetic), rounded up.  One wave per query.
 __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ Q, int B, int D, int Bpad, int Dpad,
                                                       int8_t* __restrict__ qb, double* __restrict__ qn2,
-                                                      float* __restrict__ qscale, float* __restrict__ kq, ZeroList z) {
+                                                      float* __restrict__ qscale, float2* __restrict__ kq, ZeroList z) {
     zero_words(z);
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -991,23 +1015,25 @@ __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ 
         for (int c = lane; c < D; c += 64) mxv = fmaxf(mxv, fabsf(Q[(size_t)q * D + c]));
     for (int o = 32; o > 0; o >>= 1) mxv = fmaxf(mxv, __shfl_xor(mxv, o));
     const float sq = mxv / 127.0f;
-    double ss = 0.0;
-    int l1 = 0;
+    double ss = 0.0, i2 = 0.0, e2 = 0.0;
     for (int c = lane; c < Dpad; c += 64) {
         const float v = (q < B && c < D) ? Q[(size_t)q * D + c] : 0.f;
         const int qi = sq > 0.f ? (int)rintf(v / sq) : 0;
         qb[qfrag_offset(q, c >> 5, (c >> 4) & 1, Dpad >> 5) + (c & 15)] = (int8_t)qi;
-        l1 += abs(qi);
+        const double res = sq > 0.f ? (double)v / (double)sq - qi : 0.0;
+        i2 += (double)(qi * qi);
+        e2 += res * res;
         ss += (double)v * (double)v;
     }
     for (int o = 32; o > 0; o >>= 1) {
         ss += __shfl_xor(ss, o);
-        l1 += __shfl_xor(l1, o);
+        i2 += __shfl_xor(i2, o);
+        e2 += __shfl_xor(e2, o);
     }
     if (lane == 0) {
         qn2[q] = ss;
         qscale[q] = sq;
-        kq[q] = ((float)I8_EMAX * (float)l1 + (float)(I8_EMAX * I8_EMAX) * (float)D) * 1.000001f + 0.01f;  // rounded up
+        kq[q] = make_float2((float)(sqrt(i2) * 1.000002 + 1e-4), (float)(sqrt(e2) * 1.000002 + 1e-4));
     }
 }
 
@@ -1032,8 +1058,13 @@ __global__ __launch_bounds__(256) void k_convert_q(const float* __restrict__ Q, 
 // `target` rows exceed it.  Also: the ladder step 16 / (largest maximum - tau) and cleared counters.
 // The j-th largest comes from a radix select over the 32-bit order-preserving keys (four passes of a
 // 256-bin histogram), not from a sort.  Streams without a sample hold -inf and rank last.
+// Queries that must record nothing get a threshold no score reaches: the padding of a partial batch, and on the
+// int8 shadow a query of zeros (scale 0) -- all their integer scores are 0, closer to any threshold than the integer
+// compare of the main pass resolves, so every row of the corpus would be recorded.  (A query of zeros then has no
+// candidates and is answered by the exact scan.)
 __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxima, int M, int j, float* __restrict__ tau,
-                                                  int* __restrict__ cnt, float* __restrict__ lad_inv, int* __restrict__ hist) {
+                                                  int* __restrict__ cnt, float* __restrict__ lad_inv, int* __restrict__ hist,
+                                                  int nq, const float* __restrict__ qscale) {
     __shared__ uint32_t bins[256];
     __shared__ uint32_t sel[2];  // chosen bin, rank within it
     __shared__ uint32_t smin[4];
@@ -1087,9 +1118,10 @@ __global__ __launch_bounds__(256) void k_pick_tau(const float* __restrict__ maxi
     if (tid == 0) {
         const float v = orderable_f32(~prefix);
         const float top = orderable_f32(~min(min(smin[0], smin[1]), min(smin[2], smin[3])));
-        tau[q] = v;
+        const bool off = q >= nq || (qscale && qscale[q] == 0.f);
+        tau[q] = off ? 1e30f : v;
         cnt[q * MF_CNT_STRIDE] = 0;
-        lad_inv[q] = (top > v && top - v < 1e30f) ? 16.0f / (top - v) : 0.f;
+        lad_inv[q] = (!off && top > v && top - v < 1e30f) ? 16.0f / (top - v) : 0.f;
     }
 }
 
@@ -1485,7 +1517,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_tau2 = carve((size_t)BC * sizeof(float));
     const size_t o_cnt = carve((size_t)BC * MF_CNT_STRIDE * sizeof(int));
     const size_t o_qs = carve((size_t)BC * sizeof(float));
-    const size_t o_kq = carve((size_t)BC * sizeof(float));
+    const size_t o_kq = carve((size_t)BC * sizeof(float2));
     const size_t o_lad = carve((size_t)BC * sizeof(float));
     const size_t o_hist = carve((size_t)BC * 16 * sizeof(int));
     const size_t o_cand = carve((size_t)BC * HRS_CAND_CAP_BIG * sizeof(uint64_t));
@@ -1526,7 +1558,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         } else if (i8)
             hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                                bpad, Dpad, (int8_t*)(ws + o_qb), (double*)(ws + o_qn), (float*)(ws + o_qs),
-                               (float*)(ws + o_kq), z);
+                               (float2*)(ws + o_kq), z);
         else
             hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                                bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn), z);
@@ -1534,7 +1566,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.shadow = (const char*)c->shadow;
         a.qb = (const char*)(ws + o_qb);
         a.group = nullptr;
-        a.kq = i8 ? (const float*)(ws + o_kq) : nullptr;
+        a.kq = i8 ? (const float2*)(ws + o_kq) : nullptr;
         a.N = c->N;
         a.tiles = tiles;
         a.row_offset = c->row_offset;
@@ -1552,28 +1584,33 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.prof = (long long*)ctx->stats_dev;
         a.prof_tau_shift = getenv("HRS_PROF_TAU_SHIFT") ? (float)atof(getenv("HRS_PROF_TAU_SHIFT")) : 0.f;
 #endif
-        a.raise_limit = HRS_CAND_CAP_BIG / 4;
         a.cnt = (int*)(ws + o_cnt);
         a.cand = (uint64_t*)(ws + o_cand);
         a.mask = mask;
         a.lad_inv = (const float*)(ws + o_lad);
         a.hist = (int*)(ws + o_hist);
         const int M = nslices * 2 * (TR / 32);
-        // aim at ~max(384, 6k) rows above tau; expected count ~ ss * M * -ln(1 - j/M).  The int8 shadow ranks by
-        // an upper bound that sits ~0.5 sigma above the score: of the rows recorded only about one in fourteen
-        // scores above tau itself, and k of those are needed for the proof -- hence 18k.
-        const int per_k = i8 ? 18 : 6;
-        int target = per_k * k > 384 ? per_k * k : 384;
-        int j = (target + ss - 1) / ss;
+        // aim at ~max(384, per_k * k) rows above tau; the expected count is ss * M * -ln(1 - j/M).  The int8 shadow
+        // ranks by an upper bound that sits a third of a sigma above the score at depth 384 and half a sigma at depth
+        // 1024: of the rows recorded one in four to seven scores above tau itself, and k of those are needed for the
+        // proof, for every query of the batch -- hence 18k, and 27k for the deep rows.  (HRS_PER_K overrides.)
+        static const int per_k_env = getenv("HRS_PER_K") ? atoi(getenv("HRS_PER_K")) : 0;
+        const int per_k = per_k_env > 0 ? per_k_env : (i8 ? (Dpad > 512 ? 27 : 18) : 6);
+        const int target = per_k * k > 384 ? per_k * k : 384;
+        // lists are cut (thresholds raised) where the ladder estimates more than this many rows: a quarter of what a
+        // list holds, and up to half of it where the target itself asks for more (the estimate is a coarse one)
+        a.raise_limit = target * 3 / 2 < HRS_CAND_CAP_BIG / 4 ? HRS_CAND_CAP_BIG / 4
+                      : (target * 3 / 2 < HRS_CAND_CAP_BIG / 2 ? target * 3 / 2 : HRS_CAND_CAP_BIG / 2);
+        int j = (int)ceil((double)M * (1.0 - exp(-(double)target / ((double)ss * (double)M))));
         if (j < HRS_J_MIN) j = HRS_J_MIN;
-        if (j > M / 2) j = M / 2;
+        if (j > 3 * M / 4) j = 3 * M / 4;  // (the estimate of a low quantile of few maxima is a rough one)
 
         // sampled maxima -> first tau -> sampled ladder counts -> scan (tau raised where rows come in runs)
         auto tau_steps = [&](auto&& scan) -> int {
             int r = scan(1);
             if (r) return r;
             hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt,
-                               (float*)(ws + o_lad), (int*)(ws + o_hist));
+                               (float*)(ws + o_lad), (int*)(ws + o_hist), bc, i8 ? (const float*)(ws + o_qs) : nullptr);
             // the ladder only has to be right within a factor of two: half the sample of the first pass
             const int ss2 = (int64_t)2 * ss * 4 <= min_len ? 2 * ss : ss;
             a.ss = ss2;

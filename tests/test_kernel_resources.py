@@ -89,3 +89,42 @@ def test_asm_mfma_hazard_padding(src, needle, tmp_path):
                     continue
                 since += (int(ins.split()[1]) + 1) if op == "s_nop" else 1
     assert found >= 64
+
+
+def _sregs(text):
+    regs = set()
+    for lo, hi in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        regs.update(range(int(lo), int(hi) + 1))
+    regs.update(int(n) for n in re.findall(r"\bs(\d+)\b", text))
+    return regs
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
+@pytest.mark.parametrize("src", ["hrs_mfma.hip", "hrs_exact.hip"])
+def test_scalar_load_destinations_rest_until_the_wait(src, tmp_path):
+    """A scalar load's destination registers hold stale values until lgkmcnt reaches 0, and nothing interlocks a read
+    before that.  The scan kernels issue such loads from hand-written statements whose wait is a second statement
+    further down; should the compiler ever copy or spill the destination in between, the copy would be taken before
+    the data has arrived.  Checked on the generated code of every kernel, in program order along the fall-through
+    path: from a scalar load to the next wait for lgkmcnt(0) no instruction names one of its destination registers."""
+    loads = 0
+    for name, body in _kernel_bodies(src, tmp_path).items():
+        pending = {}  # register -> index of the load
+        for idx, ins in enumerate(body):
+            op = ins.split()[0]
+            if (op == "s_waitcnt" and "lgkmcnt(0)" in ins) or op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pending = {}  # (what follows an unconditional branch is reached from elsewhere)
+                continue
+            used = _sregs(ins)
+            if op.startswith("s_load_dword") or op.startswith("s_buffer_load"):
+                dst = _sregs(ins.split(",")[0])
+                src_regs = _sregs(",".join(ins.split(",")[1:]))
+                assert not (src_regs & set(pending)), (name, idx, ins, "address from a pending destination")
+                assert not (dst & set(pending)), (name, idx, ins, "two loads into one register")
+                for r in dst:
+                    pending[r] = idx
+                loads += 1
+                continue
+            hit = used & set(pending)
+            assert not hit, (name, idx, ins, sorted(hit), body[pending[min(hit)]])
+    assert loads > 0
