@@ -372,7 +372,7 @@ def main():
     ap.add_argument("--cpu-sample-queries", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3], help="consecutive batches alternate over this many HIP streams (1: strictly back to back)")
     ap.add_argument("--layout", default="auto", choices=["auto", "replica", "shard"], help="multi-GPU layout of the headline (auto: shard -- the rows split over the ranks, one all-gather per batch)")
-    ap.add_argument("--shadow", default="auto", choices=["auto", "i8", "bf16"], help="scan shadow of the corpus (auto: int8 up to depth 512)")
+    ap.add_argument("--shadow", default="auto", choices=["auto", "i8", "bf16"], help="scan shadow of the corpus (auto: int8)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (embed, small-batch scan, other configs, text queries, replica layout)")
     args = ap.parse_args()
 
@@ -410,7 +410,7 @@ def main():
     lo, hi = shard_bounds(n_total, world, rank) if layout == "shard" else (0, n_total)
     n_local = hi - lo
     matrix, corpus, terms, postings = build_rank_state(eng, dev, n_total, D, lo, hi, args.shadow)
-    shadow = args.shadow if args.shadow != "auto" else ("i8" if D <= 512 else "bf16")
+    shadow = args.shadow if args.shadow != "auto" else "i8"
     queries = make_queries(eng, B, D, n_total, stream=rank if layout == "replica" else 0)
     q_terms, q_offs = make_query_terms(B, dev)
     torch.cuda.synchronize()

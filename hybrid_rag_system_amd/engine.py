@@ -54,7 +54,7 @@ class Corpus:
         self.matrix, self.n = matrix, n
 
     def set_shadow(self, kind):
-        """Rebuild the scan shadow: "auto" (int8 up to depth 512, else bf16), "i8", "bf16" or "none" (exact scan only)."""
+        """Rebuild the scan shadow: "auto" (int8), "i8", "bf16" or "none" (exact scan only)."""
         N.check(N.lib().hrs_corpus_shadow(self.engine._ctx, self._h, N.SHADOWS[kind], _stream()), "hrs_corpus_shadow")
 
     def norm_stats(self):

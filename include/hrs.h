@@ -56,9 +56,9 @@ enum hrs_score_mode { HRS_MODE_AUTO = 0, HRS_MODE_EXACT = 1, HRS_MODE_MFMA = 2 }
 /* The reduced-precision copy of the corpus that the MFMA scan streams.  I8: int8 with one fp32 scale
  * per 32-row group, half the bytes and twice the matrix-core rate of BF16.  The choice never changes
  * results (candidates are re-scored exactly and the top-k is proven against the shadow's rigorous
- * error bound); it only changes how many queries need the exact fallback: the int8 bound grows with
- * the depth relative to the spread of the scores, so AUTO (what hrs_corpus_register builds) is I8 up
- * to depth 512 and BF16 above. */
+ * error bound); it only changes how many rows are recorded per query and how many queries need the
+ * exact fallback.  AUTO (what hrs_corpus_register builds) is I8 for every depth the MFMA scan serves
+ * (D <= 1024). */
 enum hrs_shadow_kind { HRS_SHADOW_NONE = 0, HRS_SHADOW_BF16 = 1, HRS_SHADOW_I8 = 2, HRS_SHADOW_AUTO = 3 };
 
 #define HRS_PAD_KEY 0xFFFFFFFFFFFFFFFFull
