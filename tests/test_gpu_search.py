@@ -135,6 +135,41 @@ def test_mfma_scan_bit_exact(eng, space, shadow):
 
 
 @pytest.mark.parametrize("shadow", ["i8", "bf16"])
+def test_mfma_padding_and_zero_queries_record_nothing(eng, shadow):
+    """A partial batch is padded with queries of zeros, and a caller may send one: their integer scores are all 0,
+    nearer to any threshold than the int8 pass's integer compare resolves, so without a threshold out of reach every
+    row of the corpus is recorded for each of them (a batch of 4 over 10M rows took 115 ms instead of 0.8).  Checked
+    by results (equal to the exact scan; the query of zeros is answered by the fallback) and by the clock, with a
+    margin of more than ten times either way."""
+    n, d, k = 2_000_000, 384, 10
+    m = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    for r0 in range(0, n, 1 << 19):
+        nr = min(1 << 19, n - r0)
+        eng.synth_rows(99, r0, nr, d, out=m[r0 : r0 + nr])
+    corpus = eng.corpus(m, shadow=shadow)
+    q = eng.synth_rows(7, 0, 6, d)
+    q[3] = 0
+    for space in ("cosine", "l2"):
+        _, _, want = eng.score_topk(corpus, q, k, space=space, mode="exact", want_keys=True)
+        _, _, keys = eng.score_topk(corpus, q, k, space=space, mode="mfma", want_keys=True)
+        torch.cuda.synchronize()
+        st = eng.score_stats()
+        assert torch.equal(keys, want), (space, st)
+        assert st["fallback_queries"] <= 1 and st["overflow_queries"] == 0, (space, st)
+    q4 = q[[0, 1, 2, 4]].contiguous()
+    eng.score_topk(corpus, q4, k, space="cosine", mode="mfma")
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(5):
+        eng.score_topk(corpus, q4, k, space="cosine", mode="mfma")
+    t1.record()
+    torch.cuda.synchronize()
+    assert eng.score_stats()["fallback_queries"] == 0
+    assert t0.elapsed_time(t1) / 5 < 4.0, "a batch of 4 over 2M rows takes ~0.3 ms; 20+ ms when the padding records rows"
+    corpus.close()
+
+
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
 @pytest.mark.parametrize("d,b,space", [(1024, 200, "cosine"), (1024, 40, "l2"), (768, 130, "ip"), (512, 70, "l2"), (100, 300, "cosine")])
 def test_mfma_scan_wide_bit_exact(eng, d, b, space, shadow):
     """Other depths: every k-step count of both shadows (bf16 above 512: the four-wave kernel with
