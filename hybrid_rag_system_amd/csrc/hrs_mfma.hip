@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     // The queries of this wave: fragments, thresholds and error terms.  Requested right behind the first corpus tile
     // (the requests are independent, and a pass over a small corpus is short enough for a serial start to show).
     frag_t qf[QT][KS];
-    float tau[QT], linv[QT];
+    float tau[QT], taum[QT], linv[QT];
     float2 kq[QT];  // int8: (|qi|, |eq|) of the lane's query
     float mx[QT][WSUB];
     auto load_queries = [&]() __attribute__((always_inline)) {
@@ -232,6 +232,10 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
             for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qt][s]));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(tau[qt]), "+v"(kq[qt].x), "+v"(kq[qt].y), "+v"(linv[qt]));
+        // int8 main pass: the threshold lowered by more than the roundings of the per-block compare can add up to
+        // (the reciprocal of the group scale, one product, three fused operations: under 2.5e-7 in all)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) taum[qt] = tau[qt] - fabsf(tau[qt]) * 4e-7f;
         if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
     };
 
@@ -448,12 +452,12 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         record(hit && row < (uint32_t)a.N, ((uint64_t)(~f32_orderable(score())) << 32) | (uint32_t)(row + (uint32_t)a.row_offset), q0 + qt * 32 + i);
                     };
                     if constexpr (I8) {
-                        // maxima of the four groups of four rows, then of all sixteen: a tile with a row above the
-                        // threshold is searched group by group
-                        int m4[4];
+                        // the maximum of the sixteen rows as a chain of three-input maxima (eight instructions; a tree over
+                        // groups of four is ten); a tile with a row above the threshold is then searched group by group
+                        int m = max(max(acc[qt][0], acc[qt][1]), acc[qt][2]);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) m4[g] = max(max(acc[qt][4 * g], acc[qt][4 * g + 1]), max(acc[qt][4 * g + 2], acc[qt][4 * g + 3]));
-                        const int m = max(max(m4[0], m4[1]), max(m4[2], m4[3]));
+                        for (int r = 3; r < 15; r += 2) m = max(max(m, acc[qt][r]), acc[qt][r + 1]);
+                        m = max(m, acc[qt][15]);
                         // what the three cross terms of the quantisation residuals can add: |qi| E_g + |eq| (C_g + E_g)
                         // (the norms are rounded up by more than these two roundings can take away)
                         const float xb = fmaf(kq[qt].x, scw[sb].y, kq[qt].y * scw[sb].z);
@@ -468,18 +472,21 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                                 }
                             }
                         } else {
-                            // s_g (acc + xb) > tau  <=>  acc > tau / s_g - xb; the threshold is
-                            // pushed down by more than the rounding of these few operations, so that no
-                            // qualifying row is dropped
-                            float tf = fminf(tau[qt] * scw[sb].x, 2.1e9f);  // .x = 1 / s_g (never +inf below: no inf - inf)
-                            tf -= fabsf(tf) * 3e-7f;
-                            tf = tf - xb - 0.5f;
-                            const int ti = (int)floorf(fmaxf(tf, -2.1e9f));
+                            // s_g (acc + xb) > tau  <=>  acc > tau / s_g - xb.  Three fused operations on the lowered
+                            // threshold and a converting floor (saturating: a threshold out of reach stays one); the
+                            // half is slack for their absolute rounding, the lowering for the relative one, so that
+                            // no qualifying row is dropped.  .x = 1 / s_g
+                            float tf = fmaf(taum[qt], scw[sb].x, -0.5f);
+                            tf = fmaf(-kq[qt].x, scw[sb].y, tf);
+                            tf = fmaf(-kq[qt].y, scw[sb].z, tf);
+                            int ti;
+                            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ti) : "v"(tf));
                             if (__builtin_amdgcn_ballot_w64(m > ti) != 0) {  // wave-uniform: some lane holds such a row
                                 const float gs = scw[sb].w;  // s_g itself (.x is its reciprocal)
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
-                                    if (__builtin_amdgcn_ballot_w64(m4[g] > ti) == 0) continue;
+                                    const int m4 = max(max(acc[qt][4 * g], acc[qt][4 * g + 1]), max(acc[qt][4 * g + 2], acc[qt][4 * g + 3]));
+                                    if (__builtin_amdgcn_ballot_w64(m4 > ti) == 0) continue;
 #pragma unroll
                                     for (int r = 4 * g; r < 4 * g + 4; ++r) append(acc[qt][r] > ti, r, [&]() { return ((float)acc[qt][r] + xb) * gs; });
                                 }
