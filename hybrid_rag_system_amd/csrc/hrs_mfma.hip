@@ -452,6 +452,13 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         record(hit && row < (uint32_t)a.N, ((uint64_t)(~f32_orderable(score())) << 32) | (uint32_t)(row + (uint32_t)a.row_offset), q0 + qt * 32 + i);
                     };
                     if constexpr (I8) {
+#ifdef HRS_SCAN_NOEPI  // timing only: a main pass that never looks at its accumulators (no results)
+                        if (MODE == 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[qt][r]));
+                            continue;
+                        }
+#endif
                         // the maximum of the sixteen rows as a chain of three-input maxima (eight instructions; a tree over
                         // groups of four is ten); a tile with a row above the threshold is then searched group by group
                         int m = max(max(acc[qt][0], acc[qt][1]), acc[qt][2]);
