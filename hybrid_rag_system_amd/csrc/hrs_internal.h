@@ -12,9 +12,9 @@
 
 #define HRS_NUM_CU 256      // MI355X: 8 XCDs x 32 CUs
 #define HRS_EXACT_CB 512    // per-query candidate buffer of the exact scan (keys)
-#define HRS_CAND_CAP 2048   // per-query candidate list of the MFMA scan as the fast re-score kernel sorts it
-#define HRS_RESCORE_MAX 512  // largest prefix the fast re-score kernel re-scores, a power of two (its LDS stays
-                             // under 64 KB: it shares a CU with a 96 KB scan workgroup)
+#define HRS_CAND_CAP 4096   // per-query candidate list of the MFMA scan as the fast re-score kernel sorts it
+#define HRS_RESCORE_MAX 1024  // largest prefix the fast re-score kernel re-scores, a power of two (with these two its
+                              // LDS is exactly 80 KB: two workgroups per CU, as with half of each)
 #define HRS_CAND_CAP_BIG 8192  // capacity of the list in memory (longer lists go to the large re-score kernel)
 #define HRS_RESCORE 256     // candidates re-scored exactly per query
 #define HRS_MAX_STREAMS 1024  // per-query running maxima written by the sampling pass

@@ -1160,6 +1160,7 @@ struct SelectArgs {
     int64_t* rows_out;   // nullable [B][k]: ... and rows (-1 and +inf where fewer than k rows exist)
     int32_t* qlist;      // queue of queries for the exact fallback
     int32_t* nflag;
+    int large_first;     // every query goes to the large variant at once (deep rows and a large k: see the launcher)
     int32_t* qlist2;     // queue (chunk-local indices) of queries deferred to the large variant; [0] of nflag2 = count
     int32_t* nflag2;
     long long* stats;    // [0] fallbacks, [1] max candidates, [2] overflows
@@ -1167,7 +1168,7 @@ struct SelectArgs {
 };
 
 // Two sizes of the same kernel.  The small one (lists up to HRS_CAND_CAP, re-scored prefix up to HRS_RESCORE_MAX
-// rows, 60 KB of LDS: one workgroup fits beside a scan workgroup on a CU) serves every query first; a query whose list is longer or whose
+// rows, 80 KB of LDS: two workgroups per CU) serves every query first; a query whose list is longer or whose
 // prefix would have to grow further -- runs of near-duplicate rows around the top -- is deferred to the
 // large one (lists up to HRS_CAND_CAP_BIG, prefix up to 4096, one workgroup per CU), and only what that
 // cannot prove goes to the exact scan.
@@ -1186,13 +1187,18 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
     uint64_t* ek = s + SCAP;                                 // [RMAX]
     float* qs = (float*)(ek + RMAX);                         // [1024] the query (D <= 1024 on this path)
     char* stage = (char*)(qs + 1024);                        // per wave: 64 rows x one 128-byte line (+16 pad)
-    __shared__ int need_s, ok;
+    // two words that all threads share live in the padding of the first staged row (bytes 128..143 of a 144-byte row
+    // are never written or read by the row fetches): the small variant's LDS is then exactly half a CU's
+    int& need_s = *(int*)(stage + 128);
+    int& ok = *(int*)(stage + 132);
     const int q = a.qbase + ql;      // query in the caller's batch
     const int tid = threadIdx.x;
     const int craw = a.cnt[ql * MF_CNT_STRIDE];
     const int c = craw < SCAP ? craw : SCAP;
     const bool overflow = craw > HRS_CAND_CAP_BIG;  // rows above tau were dropped: only the exact scan can answer
-    if (!BIG && craw > SCAP && !overflow) {         // longer than this variant sorts: the large one takes it
+    // longer than this variant sorts, or a call whose proofs are expected to need a longer re-scored prefix than this
+    // variant holds (it would re-score 512 rows and then hand the query over all the same): the large one takes it
+    if (!BIG && !overflow && (craw > SCAP || a.large_first)) {
         if (tid == 0) a.qlist2[atomicAdd(a.nflag2, 1)] = ql;
         return;
     }
@@ -1206,10 +1212,15 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
     const float* qr = a.Q + (size_t)q * a.D;
     for (int t = tid; t < a.D; t += 256) qs[t] = qr[t];
     auto sort_keys = [&](uint64_t* p, int n) __attribute__((always_inline)) {
-        if (n <= 2048)
+        if (n <= 2048) {
             bitonic_sort_u64_256t(p, n, tid);
-        else
-            bitonic_sort_u64(p, n, tid, 256);
+        } else if (n == 4096) {  // 16 keys per thread in registers
+            __syncthreads();
+            bitonic_sort_u64_regs<16>(p, tid);
+        } else if constexpr (BIG) {  // 32 (this variant runs one workgroup per CU)
+            __syncthreads();
+            bitonic_sort_u64_regs<32>(p, tid);
+        }
     };
     sort_keys(s, n2);
 
@@ -1425,7 +1436,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
 // deferred queries (device-side count, nearly always zero -- and a thousand workgroups of 100 KB of LDS each are slow
 // to dispatch and retire beside a scan even when they leave at once).
 template <int SPACE, bool BIG>
-__global__ __launch_bounds__(256) void k_select_rescore(SelectArgs a) {
+__global__ __launch_bounds__(256, BIG ? 1 : 2) void k_select_rescore(SelectArgs a) {  // (two small ones share a CU)
     if (!BIG) {
         select_rescore_one<SPACE, false>(a, blockIdx.x);
     } else {
@@ -1730,6 +1741,10 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.nflag = nflag;
         s.stats = (long long*)ctx->stats_dev;
         s.qbase = qbase;
+        // a proof needs about a quarter of the target re-scored (the rows whose bound reaches the k-th exact score); for
+        // deep rows and a large k that is often more than the small variant's prefix, and what it has re-scored by
+        // then (4 KB a row) is read again by the large one
+        s.large_first = i8 && Dpad > 512 && per_k * k / 4 > HRS_RESCORE_MAX / 2;
         s.qlist2 = (int32_t*)(ws + o_q2) + 64;
         s.nflag2 = (int32_t*)(ws + o_q2);
         if (space == HRS_SPACE_L2)
