@@ -1554,7 +1554,6 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     int32_t* qlist = (int32_t*)(ws + o_qlist);
 
     const int64_t tiles = (c->N + TR - 1) / TR;
-    if (do_scan && ctx->peer && ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
     // The tail of a two-phase call runs right behind its own main pass, beside the sampled passes of the scan that
     // waits for this one.  (HRS_TAIL_LATE=1 holds it until that scan has set its thresholds, so that it is queued
     // under that scan's main pass; it cannot share a SIMD with two scan waves -- 2 x 200 + 128 registers -- and when
@@ -1587,6 +1586,10 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         else
             hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                                bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn), z);
+        // the scans of two contexts take turns -- but the conversion of the queries does not have to wait
+        if (do_scan && qbase == 0 && ctx->peer) {
+            if (ctx->peer->scan_recorded) HRS_CHECK_HIP(hipStreamWaitEvent(st, ctx->peer->scan_done, 0));
+        }
         MfmaArgs a;
         a.shadow = (const char*)c->shadow;
         a.qb = (const char*)(ws + o_qb);
