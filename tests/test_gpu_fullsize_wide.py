@@ -66,3 +66,19 @@ def test_shard_of_100m_split_in_two_merges_to_the_same(world):
     assert torch.equal(merged, want)
     for cp in keep:
         cp.close()
+
+
+def test_shard_of_100m_bf16_shadow_gives_the_same_keys(world):
+    """The shadow is a choice of speed, never of results: the depth-1024 bf16 kernel (the default at this depth before
+    the int8 bound was tightened) returns the keys of the int8 scan, at full size.  (Runs last: it rebuilds the shadow.)"""
+    eng, m, corpus, q, planted = world
+    _, _, want = eng.score_topk(corpus, q, K, space="cosine", mode="mfma", want_keys=True)
+    corpus.set_shadow("bf16")
+    try:
+        _, _, got = eng.score_topk(corpus, q, K, space="cosine", mode="mfma", want_keys=True)
+        torch.cuda.synchronize()
+        st = eng.score_stats()
+        assert st["overflow_queries"] == 0 and st["fallback_queries"] <= 8, st
+        assert torch.equal(got, want)
+    finally:
+        corpus.set_shadow("auto")

@@ -199,11 +199,13 @@ def test_mfma_scan_wide_bit_exact(eng, d, b, space, shadow):
     corpus.close()
 
 
+@pytest.mark.parametrize("shadow", ["i8", "bf16"])
 @pytest.mark.parametrize("b,space", [(1024, "cosine"), (640, "l2")])
-def test_mfma_scan_wide_large_batch_top100(eng, b, space):
-    """The shape of a 100M x 1024 corpus' shard query (batch 1024, top-100, bf16 shadow) at a size the oracle
-    finishes in seconds: batches of 512 and more take the one-barrier-per-tile schedule of the depth-1024 kernel
-    (eight resp. five query groups of 128), and every key equals the oracle's."""
+def test_mfma_scan_wide_large_batch_top100(eng, b, space, shadow):
+    """The shape of a 100M x 1024 corpus' shard query (batch 1024, top-100) at a size the oracle finishes in seconds,
+    and every key equals the oracle's.  bf16 shadow: batches of 512 and more take the one-barrier-per-tile schedule of
+    the depth-1024 kernel (eight resp. five query groups of 128).  int8 shadow (the default at this depth): the 32-step
+    int8 kernel, lists of ~2700 rows, every query re-scored by the large variant of the re-score kernel."""
     rng = np.random.default_rng(1000 + b)
     n, d, k = 120_007, 1024, 100
     C = _unit(rng, n, d)  # unit rows, as embeddings are: the cosine proof bounds a row's norm by the corpus' extremes
@@ -216,7 +218,7 @@ def test_mfma_scan_wide_large_batch_top100(eng, b, space):
     C[60_000] = C[0]
     Q[b - 1] = C[0] / np.linalg.norm(C[0])
     want = so.topk_keys(Q, C, k, space)
-    corpus = eng.corpus(torch.from_numpy(C).cuda())  # AUTO: bf16 above depth 512
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow=shadow)
     _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
     torch.cuda.synchronize()
     st = eng.score_stats()
