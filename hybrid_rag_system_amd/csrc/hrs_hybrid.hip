@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_keyword_counts(const int64_t* __restric
         const int t0 = q_term_offs[b], t1 = q_term_offs[b + 1];
         for (int tb = t0; tb < t1; tb += 64) {
             const int nt = min(64, t1 - tb);
-            const int my = lane < nt ? q_terms[tb + lane] : -1;  // this round's query terms, one per lane
+            const int my = lane < nt ? q_terms[tb + lane] : -1;  // the query terms of this pass over them, one per lane
             uint64_t found = 0;                                    // bit j: query term tb + j occurs in the row
             for (int64_t p = p0; p < p1; p += 64) {
                 const int dt = p + lane < p1 ? term_ids[p + lane] : -2;
