@@ -134,6 +134,45 @@ def test_mfma_scan_bit_exact(eng, space, shadow):
     corpus.close()
 
 
+@pytest.mark.parametrize("space", ["ip", "l2"])
+@pytest.mark.parametrize("d", [384, 1024])
+def test_int8_bound_holds_when_the_quantisation_residuals_align(eng, d, space):
+    """The int8 scan drops a row only if an upper bound of its score is below the threshold; the bound takes the
+    three cross terms of the quantisation residuals by Cauchy-Schwarz, which random residuals never come near.
+    Here they are made to: every row is (integer vector + 7/16 sign(q)) x 2^-7, so its residual is parallel to the
+    integer vector of the first queries (all +-127) and the bound is met with equality up to its rounding margin;
+    the other queries carry a residual parallel to one row's integer vector.  Were any norm in the bound a little
+    too small (a rounding the wrong way, a lane left out of a reduction), the rows that ought to win would score
+    above their bound and could be dropped; the keys must equal the oracle's."""
+    rng = np.random.default_rng(5 + d)
+    n, b, k = 20_000, 8, 10
+    sign = rng.choice([-1.0, 1.0], d).astype(np.float32)
+    ci = rng.integers(-100, 101, (n, d)).astype(np.float32)
+    ci[::32, 0] = 127.0  # every 32-row group's scale is exactly 2^-7
+    C = ((ci + np.float32(0.4375) * sign) * np.float32(2.0**-7)).astype(np.float32)
+    C[::32, 0] = 127.0 * 2.0**-7
+    Q = np.empty((b, d), np.float32)
+    Q[:4] = sign * np.float32(2.0**-3)                      # integer vector +-127, no residual
+    Q[1] *= 3.0
+    Q[2, : d // 2] *= 0.5                                     # (half the components at +-64 after quantisation)
+    Q[3] = -Q[3]
+    for j in range(4, b):                                     # integer part random, residual parallel to a row's integers
+        qi = rng.integers(-126, 127, d).astype(np.float32)
+        qi[0] = 127.0
+        row = ci[1 + 37 * j]
+        Q[j] = (qi + np.float32(0.4375) * np.sign(row)) * np.float32(2.0**-5)
+        Q[j, 0] = 127.0 * 2.0**-5
+    want = so.topk_keys(Q, C, k, space)
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), shadow="i8")
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, space=space, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    st = eng.score_stats()
+    assert np.array_equal(_keys(keys), want), st
+    if space == "ip":
+        assert st["fallback_queries"] == 0, st  # answered by the int8 scan and its proof, not by the exact fallback
+    corpus.close()
+
+
 @pytest.mark.parametrize("shadow", ["i8", "bf16"])
 def test_mfma_padding_and_zero_queries_record_nothing(eng, shadow):
     """A partial batch is padded with queries of zeros, and a caller may send one: their integer scores are all 0,
