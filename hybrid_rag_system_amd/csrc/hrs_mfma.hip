@@ -1,22 +1,23 @@
-// Large-batch scoring on the matrix cores: bf16 MFMA scan with a threshold filter, then an exact
-// fp64 re-score of the surviving candidates and a proof that the top-k is the exact one.
+// Large-batch scoring on the matrix cores: an MFMA scan over a reduced-precision shadow of the corpus (int8 or
+// bf16) with a threshold filter, then an exact fp64 re-score of the surviving candidates and a proof that the
+// top-k is the exact one.
 //
-//   1. k_convert_q      queries fp32 -> bf16 (+ squared norms)
-//   2. k_mfma_scan<PRE> a sampled subset of corpus tiles: per (query, stream) running maximum
-//   3. k_pick_tau       per query: tau = j-th largest stream maximum  (a LOWER bound of the j-th
-//                       largest sampled score), chosen so that a few hundred rows exceed it
-//   4. k_mfma_scan<MAIN> the whole corpus: every (query, row) with score > tau is appended to the
-//                       query's candidate list (global atomics; a few hundred per query)
-//   5. k_select_rescore per query: sort candidates by approximate score, re-score the best 256
-//                       exactly (fp64, the oracle's operations), sort by (fp32 distance, row) and
-//                       accept iff the k-th exact distance is provably below anything outside the
-//                       re-scored set (bf16 rounding bound); otherwise the query is queued for
-//   6. the exact scan   (hrs_exact.hip), driven by the device-side queue; no host round trip.
+//   1. k_convert_q[_i8]  queries fp32 -> int8 / bf16 in MFMA operand order (+ squared norms, scales, error norms)
+//   2. k_mfma_scan<1>    a sampled subset of corpus tiles: per (query, stream) running maximum
+//   3. k_pick_tau        per query: tau = j-th largest stream maximum (a LOWER bound of the j-th largest sampled
+//                        score), chosen so that a few hundred rows exceed it
+//   4. k_mfma_scan<2>    a second sample: how many sampled scores exceed tau, in sixteen steps (for corpora whose
+//                        rows come in runs of neighbours: the main pass raises tau where a list would overflow)
+//   5. k_mfma_scan<0>    the whole corpus: every (query, row) with (an upper bound of the) score > tau goes to the
+//                        query's candidate list (staged per wave in LDS, appended 64 at a time)
+//   6. k_select_rescore  per query: sort the candidates by recorded score, re-score the best exactly (fp64, the
+//                        oracle's operations), sort by (fp32 distance, row) and accept iff the k-th exact distance
+//                        is provably below anything outside the re-scored set; otherwise the query is queued for
+//   7. the exact scan    (hrs_exact.hip), driven by the device-side queue; no host round trip.
 //
-// Scan kernel geometry (per CU: one workgroup of 8 waves, two per SIMD):
-// each wave keeps the B-operand fragments of 32 queries for the WHOLE depth D in registers (D/4
-// VGPRs); 64-row corpus tiles (bf16) stream through a 3-deep LDS ring by LDS-DMA and are the A
-// operand, shared by the 8 waves (256 queries per workgroup).  D(32x32) = A(corpus rows) x B(queries)
+// Scan kernel geometry (per CU: one workgroup of 8 waves, two per SIMD): each wave keeps the B-operand fragments
+// of 32 or 64 queries for the WHOLE depth in registers; 64-row corpus tiles stream through an LDS ring (3 to 5
+// tiles deep) by LDS-DMA and are the A operand, shared by the 8 waves.  D(32x32) = A(corpus rows) x B(queries)
 // puts the query on the lane, so the filter threshold is one VGPR.
 #include <type_traits>
 
