@@ -59,7 +59,8 @@ template <> struct scan_types<true> { typedef i32x4 frag; typedef i32x16 acc; };
 // The kernels with two query tiles per wave serve large batches, which the matrix cores bound.  There the
 // workgroup barrier at every tile boundary costs a tenth of the time (eight waves wait for the slowest), so
 // these kernels synchronise at every second boundary instead: four buffers, two tiles requested at a time.
-// 96 KB at depth 384, which leaves LDS for a re-score workgroup of the previous batch on the CU.
+// 96 KB at depth 384.  (A re-score workgroup of the previous batch does not share the CU either way: two scan
+// waves per SIMD leave it too few registers.)
 constexpr bool scan_pairs(int qt) { return qt == 2; }
 // Rows above the threshold are staged in LDS, every wave in a region of its own with the fill level in a scalar
 // register (slots come from a ballot and a lane count: no atomic, no wait), and go to the per-query lists in
