@@ -59,7 +59,10 @@ __global__ void k_queries_f64(const float* __restrict__ Q, int64_t n, double* __
 // queries per pass the LDS copy costs 64 of the 72 LDS reads per thread and 32-float segment -- every lane reads the
 // same 16 bytes, but a read instruction takes its share of the LDS pipe all the same -- and held the scan at 4.1 TB/s
 // where the same loop without them streams 5.8.
-template <int SPACE, int BQ, bool SQ = false>
+// EXT: the forms only the extended entry points use (a resume key per query, a mask per query, a mask compared for
+// equality with a value).  They are compiled out of the plain scan: their conditional global loads at the end of a tile
+// make the compiler place a vmcnt(0) in front of the loop's counted wait, which drains the DMA ring at every segment.
+template <int SPACE, int BQ, bool SQ = false, bool EXT = false>
 __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
     typedef const __attribute__((address_space(4))) double* qd_ptr;
     constexpr int NQT = BQ > ESLOTS ? BQ / ESLOTS : 1;  // queries per thread
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             qidx[tid] = a.qlist ? a.qlist[j] : j;
             cnt[tid] = 0;
             tau[tid] = HRS_PAD_KEY;
-            aft[tid] = a.after ? a.after[qidx[tid]] : 0ull;
+            if (EXT) aft[tid] = a.after ? a.after[qidx[tid]] : 0ull;
         }
         __syncthreads();
         for (int e = tid; e < BQ * D; e += 256) qf32[e] = a.Q[(size_t)qidx[e / D] * D + e % D];
@@ -283,13 +286,17 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                 const int64_t tile = tile_begin + step / nchunks;
                 const int64_t row = tile * ER + row_t;
                 bool live = row < a.N && qslot < NSL;
-                if (live && a.mask && a.mask_qstride == 0) live = a.mask_eq < 0 ? a.mask[row] != 0 : a.mask[row] == a.mask_eq;
+                if (EXT) {
+                    if (live && a.mask && a.mask_qstride == 0) live = a.mask_eq < 0 ? a.mask[row] != 0 : a.mask[row] == a.mask_eq;
+                } else {
+                    if (live && a.mask) live = a.mask[row] != 0;
+                }
                 if (live) {
                     const uint32_t grow = (uint32_t)(row + a.row_offset);
 #pragma unroll
                     for (int b = 0; b < NQT; ++b) {
                         const int qb_i = qslot + NSL * b;
-                        if (a.mask_qstride) {  // a mask per query (rows grouped by their keyword match count)
+                        if (EXT && a.mask_qstride) {  // a mask per query (rows grouped by their keyword match count)
                             const uint8_t mv = a.mask[(int64_t)qidx[qb_i] * a.mask_qstride + row];
                             if (a.mask_eq < 0 ? mv == 0 : mv != a.mask_eq) continue;
                         }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                             d = (nqv == 0.0 || ncacc == 0.0) ? 1.0 : 1.0 - acc[b] / (sqrt(nqv) * sqrt(ncacc));
                         }
                         const uint64_t key = pack_key((float)d, grow);
-                        if (key < tau[qb_i] && (!a.after || key > aft[qb_i])) {
+                        if (key < tau[qb_i] && (!EXT || !a.after || key > aft[qb_i])) {
                             const int pos = atomicAdd(&cnt[qb_i], 1);
                             cand[qb_i * HRS_EXACT_CB + pos] = key;  // pos < CB: cnt <= CB - ER before a tile
                         }
@@ -420,27 +427,32 @@ __global__ __launch_bounds__(256) void k_merge_lists_serial(MergeArgs a) {
     }
 }
 
-template <int SPACE, int BQ, bool SQ = false>
+template <int SPACE, int BQ, bool SQ = false, bool EXT = false>
 static int launch_exact_t(const ExactArgs& a, int grid, int device, hipStream_t st) {
     size_t lds = ENBUF * ESEG_BYTES + EQ_FLOATS * sizeof(float) + 2 * BQ * EDC * sizeof(double) +
                  BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (2 * sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
     static hrs_per_device_once attr;  // the attribute belongs to the function on ONE device
     if (attr.need(device)) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ, SQ>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ, SQ, EXT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.done(device);
     }
-    hipLaunchKernelGGL((k_exact_scan<SPACE, BQ, SQ>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_exact_scan<SPACE, BQ, SQ, EXT>), dim3(grid), dim3(256), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
 
+template <int SPACE, bool EXT>
+static int launch_exact_e(const ExactArgs& a, int grid, int bq, int device, hipStream_t st) {
+    if (bq >= 4 && a.qd) return launch_exact_t<SPACE, 4, true, EXT>(a, grid, device, st);
+    if (bq >= 4) return launch_exact_t<SPACE, 4, false, EXT>(a, grid, device, st);
+    if (bq >= 2) return launch_exact_t<SPACE, 2, false, EXT>(a, grid, device, st);
+    return launch_exact_t<SPACE, 1, false, EXT>(a, grid, device, st);
+}
 template <int SPACE>
 static int launch_exact_s(const ExactArgs& a, int grid, int bq, int device, hipStream_t st) {
-    if (bq >= 4 && a.qd) return launch_exact_t<SPACE, 4, true>(a, grid, device, st);
-    if (bq >= 4) return launch_exact_t<SPACE, 4>(a, grid, device, st);
-    if (bq >= 2) return launch_exact_t<SPACE, 2>(a, grid, device, st);
-    return launch_exact_t<SPACE, 1>(a, grid, device, st);
+    if (a.after || a.mask_qstride || a.mask_eq >= 0) return launch_exact_e<SPACE, true>(a, grid, bq, device, st);
+    return launch_exact_e<SPACE, false>(a, grid, bq, device, st);
 }
 
 // Exact top-k of queries Q[qlist[0..nq)] (or Q[0..B) when qlist is null); nq may live on the device
