@@ -314,8 +314,52 @@ def build_rank_state(eng, dev, n_total, D, lo, hi, shadow):
     return matrix, corpus, terms, postings
 
 
+def check_step(eng, corpus, terms, lo, queries, q_terms, q_offs, out, n_keep, space, sharded, sample=24):
+    """What the timed steps computed, checked on a sample of the batch at full size (the run aborts otherwise):
+    the candidates equal the fp64 streaming scan's (single GPU), their keyword counts equal a recount on the host
+    from the rows' own term lists, and order and fused scores equal the helper's arithmetic
+    (scripts/chromadb_helper.py:302-325) in Python floats, bit for bit."""
+    B, c = out["cand_rows"].shape
+    sel = sorted(set(np.linspace(0, B - 1, sample).astype(int).tolist()) | {0, 10, 20})  # every 10th query is a planted one
+    sel_t = torch.tensor(sel, device=queries.device)
+    rows = out["cand_rows"][sel_t].cpu().numpy()
+    dist = out["cand_dist"][sel_t].cpu().numpy()
+    counts = out["cand_counts"][sel_t].cpu().numpy()
+    comb = out["combined"][sel_t].cpu().numpy()
+    perm = out["perm"][sel_t].cpu().numpy()
+    if not sharded:
+        xd, xr = eng.score_topk(corpus, queries[sel_t].contiguous(), c, space=space, mode="exact")
+        if not (torch.equal(xr.cpu(), torch.from_numpy(rows)) and np.array_equal(xd.cpu().numpy().view(np.uint32), dist.view(np.uint32))):
+            raise SystemExit("headline check: the candidates differ from the exact scan's")
+    qo = q_offs.cpu().numpy()
+    qt = q_terms.cpu().numpy()
+    n_local = terms.shape[0]
+    for i, b in enumerate(sel):
+        mine = qt[qo[b] : qo[b + 1]].tolist()
+        m = len(mine)
+        local = (rows[i] >= lo) & (rows[i] < lo + n_local)
+        if local.any():
+            rt = terms[torch.from_numpy(rows[i][local] - lo).to(terms.device)].cpu().numpy()
+            want = np.array([sum(1 for t in mine if t in set(r.tolist())) for r in rt])
+            if not np.array_equal(want, counts[i][local]):
+                raise SystemExit(f"headline check: keyword counts of query {b} differ from the recount")
+        scored = []
+        for j in range(c):
+            if rows[i][j] < 0:
+                continue
+            d = float(dist[i][j])
+            sem = max(0, 1 - d)
+            kw = int(counts[i][j]) / m if m else 0.0
+            scored.append((sem * (1 - 0.3) + kw * 0.3, j))
+        scored.sort(key=lambda x: x[0], reverse=True)  # stable, as list.sort in the helper
+        scored = scored[:n_keep]
+        if [j for _, j in scored] != perm[i][: len(scored)].tolist() or not np.array_equal(np.array([v for v, _ in scored], np.float64).view(np.uint64), comb[i][: len(scored)].view(np.uint64)):
+            raise SystemExit(f"headline check: order or fused scores of query {b} differ from the helper's arithmetic")
+    return f"{len(sel)} sampled queries of the last timed batch: candidates equal the fp64 exact scan's" + ("" if not sharded else " (skipped: sharded)") + ", keyword counts equal a host recount from the rows' term lists, order and fused scores equal Python-float arithmetic bit for bit"
+
+
 def timed_run(engines, corpus, postings, group, queries, q_terms, q_offs, n_keep, args, world, rehearsal, dev):
-    """W warmup + K timed steps through the two-stream pipeline -> (max-over-ranks seconds, kernel ms, launches, stats, pipeline)."""
+    """W warmup + K timed steps through the two-stream pipeline -> (max-over-ranks seconds, kernel ms, launches, stats, pipeline, last result)."""
     import torch.distributed as dist
 
     eng = engines[0]
@@ -343,7 +387,7 @@ def timed_run(engines, corpus, postings, group, queries, q_terms, q_offs, n_keep
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    searcher.drain()
+    last = searcher.drain()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -353,7 +397,7 @@ def timed_run(engines, corpus, postings, group, queries, q_terms, q_offs, n_keep
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, kern_ms, launches, stats, searcher
+    return elapsed, kern_ms, launches, stats, searcher, last
 
 
 def main():
@@ -418,9 +462,10 @@ def main():
     # batch i runs on stream i % streams (one engine = one set of workspaces per stream); the dominant
     # kernel is timed on the first engine's launches
     engines = [eng] + [Engine(local_rank) for _ in range(max(args.streams, 1) - 1)]
-    elapsed, kern_ms, launches, stats, searcher = timed_run(engines, corpus, postings, None if layout == "shard" else False, queries, q_terms,
-                                                            q_offs, n_keep, args, world, rehearsal, dev)
+    elapsed, kern_ms, launches, stats, searcher, last = timed_run(engines, corpus, postings, None if layout == "shard" else False, queries, q_terms,
+                                                                  q_offs, n_keep, args, world, rehearsal, dev)
     bytes_gathered = searcher.lanes[0][0].bytes_gathered
+    checked = check_step(eng, corpus, terms, lo, queries, q_terms, q_offs, last, n_keep, args.space, layout == "shard" and world > 1)
 
     # the replica layout beside a sharded headline (when the whole corpus fits one GPU next to the shard)
     replica = None
@@ -431,7 +476,7 @@ def main():
         torch.cuda.empty_cache()
         matrix, corpus, terms, postings = build_rank_state(eng, dev, n_total, D, 0, n_total, args.shadow)
         rq = make_queries(eng, B, D, n_total, stream=rank)
-        r_elapsed, _, _, _, _ = timed_run(engines, corpus, postings, False, rq, q_terms, q_offs, n_keep, args, world, rehearsal, dev)
+        r_elapsed, _, _, _, _, _ = timed_run(engines, corpus, postings, False, rq, q_terms, q_offs, n_keep, args, world, rehearsal, dev)
         replica = {"queries_per_s": B * args.steps * world / r_elapsed, "ms_per_step": r_elapsed / args.steps * 1e3, "scaling": "weak",
                    "parallelism": f"query-parallel x{world}: corpus replicated, {B} queries per GPU per step, no data-path collective"}
 
@@ -496,6 +541,7 @@ def main():
             "roofline": roof,
             "fallback_queries_per_batch": stats["fallback_queries"],
             "max_candidates": stats["max_candidates"],
+            "checked": checked,
         }
         if world > 1:
             line["rccl"] = {"ranks": world, "backend": "gloo (rehearsal)" if rehearsal else f"{backend} (RCCL)", "collective": "all_gather_into_tensor, one per batch, on its own stream" if layout == "shard" else None,

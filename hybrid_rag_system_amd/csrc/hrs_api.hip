@@ -25,22 +25,23 @@ extern "C" int hrs_last_error(char* buf, size_t n) {
     return (int)len;
 }
 
+// Grows a workspace without waiting for the device.  hipFree synchronises the whole device, and a peer context may
+// be in the middle of its pipeline on another stream, so the outgrown block is neither waited for nor freed here: it
+// is parked on the context (kernels already queued may still use it) and released by hrs_ctx_destroy, behind that
+// call's own device synchronisation.  Blocks double, so all the parked blocks of a workspace together are smaller
+// than the block that replaced them.
 int hrs_ws_reserve(hrs_ctx* ctx, hrs_workspace* ws, size_t bytes) {
-    (void)ctx;
     if (ws->bytes >= bytes) return HRS_OK;
-    if (ws->ptr) {
-        HRS_CHECK_HIP(hipDeviceSynchronize());
-        HRS_CHECK_HIP(hipFree(ws->ptr));
-        ws->ptr = nullptr;
-        ws->bytes = 0;
-    }
-    size_t want = bytes + bytes / 4 + 4096;
-    hipError_t e = hipMalloc(&ws->ptr, want);
+    size_t want = bytes + 4096;
+    if (want < 2 * ws->bytes) want = 2 * ws->bytes;
+    void* fresh = nullptr;
+    hipError_t e = hipMalloc(&fresh, want);
     if (e != hipSuccess) {
         hrs_set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
-        ws->ptr = nullptr;
-        return HRS_ERR_NOMEM;
+        return HRS_ERR_NOMEM;  // the old block stays in place and usable
     }
+    if (ws->ptr) ctx->retired.push_back(ws->ptr);
+    ws->ptr = fresh;
     ws->bytes = want;
     return HRS_OK;
 }
@@ -148,6 +149,7 @@ extern "C" int hrs_ctx_destroy(hrs_ctx* ctx) {
     if (ctx->ws_mfma.ptr) (void)hipFree(ctx->ws_mfma.ptr);
     if (ctx->ws_keys.ptr) (void)hipFree(ctx->ws_keys.ptr);
     if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+    for (void* p : ctx->retired) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_stop) (void)hipEventDestroy(e);
     delete ctx;

@@ -26,10 +26,11 @@ __global__ __launch_bounds__(256) void k_keyword_counts(const int64_t* __restric
             const int my = lane < nt ? q_terms[tb + lane] : -1;  // the query terms of this pass over them, one per lane
             uint64_t found = 0;                                    // bit j: query term tb + j occurs in the row
             for (int64_t p = p0; p < p1; p += 64) {
-                const int dt = p + lane < p1 ? term_ids[p + lane] : -2;
+                const bool have = p + lane < p1;  // lanes beyond the row compare nothing (a query term may be any int32)
+                const int dt = have ? term_ids[p + lane] : 0;
                 for (int j = 0; j < nt; ++j) {
                     const int qt = __builtin_amdgcn_readlane(my, j);
-                    if (__builtin_amdgcn_ballot_w64(dt == qt) != 0) found |= 1ull << j;
+                    if (__builtin_amdgcn_ballot_w64(have && dt == qt) != 0) found |= 1ull << j;
                 }
             }
             n += __builtin_popcountll(found);
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256) void k_match_counts(const int64_t* __restrict_
                                                       const int32_t* __restrict__ q_term_offs, uint8_t* __restrict__ counts) {
     const int b = blockIdx.y;
     uint32_t* row0 = (uint32_t*)(counts + (int64_t)b * N);  // N is a multiple of 4 here (the caller pads the row pitch)
-    for (int t = q_term_offs[b]; t < q_term_offs[b + 1]; ++t) {
+    // a row's count is one byte: at most 255 terms of a query are counted (the rest could carry into the next row's byte)
+    const int t_begin = q_term_offs[b], t_end = min(q_term_offs[b + 1], t_begin + 255);
+    for (int t = t_begin; t < t_end; ++t) {
         const int term = q_terms[t];
         if (term < 0 || term >= V) continue;
         const int64_t p0 = term_offs[term], p1 = term_offs[term + 1];

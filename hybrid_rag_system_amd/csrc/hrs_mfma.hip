@@ -967,32 +967,47 @@ int hrs_build_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, hipStream_t st) {
 // allocation doubles when it is full, so a long run of small appends costs O(rows appended) in total.
 int hrs_append_shadow(hrs_ctx* ctx, hrs_corpus* c, const float* C, int64_t N_new, hipStream_t st) {
     const int64_t N_old = c->N;
-    c->C = C;
-    c->N = N_new;
-    if (N_new == N_old) return HRS_OK;
-    if (N_old == 0 || (!c->shadow && !c->norm_stats)) return hrs_build_shadow(ctx, c, c->want_kind, st);
-    c->Npad = shadow_npad(N_new);
+    if (N_new == N_old) {
+        c->C = C;
+        return HRS_OK;
+    }
+    if (N_old == 0 || (!c->shadow && !c->norm_stats)) {
+        c->C = C;
+        c->N = N_new;
+        return hrs_build_shadow(ctx, c, c->want_kind, st);
+    }
+    const int64_t Npad_new = shadow_npad(N_new);
     if (!c->shadow) {  // no shadow by choice or depth: the statistics alone
+        c->C = C;
+        c->N = N_new;
+        c->Npad = Npad_new;
         hipLaunchKernelGGL(k_row_norm_stats, dim3((unsigned)((N_new - N_old + 15) / 16)), dim3(256), 0, st, c->C, c->N, c->D,
                            (unsigned long long*)c->norm_stats, N_old);
         HRS_CHECK_HIP(hipGetLastError());
         return HRS_OK;
     }
     const int64_t r_from = N_old / 32 * 32;
-    if (c->Npad > c->cap) {
+    if (Npad_new > c->cap) {
+        // The corpus keeps describing its old rows until the larger shadow exists and holds them: a failure below leaves
+        // the handle as it was (N_old rows over the old matrix), never one that claims rows its shadow does not cover.
         int64_t cap = c->cap * 2;
-        if (cap < c->Npad) cap = c->Npad;
+        if (cap < Npad_new) cap = Npad_new;
         void* ns = nullptr;
         float4* ng = nullptr;
         int rc = shadow_alloc(c, cap, &ns, &ng);
         if (rc) return rc;
         const size_t esz = c->kind == HRS_SHADOW_I8 ? 1 : sizeof(__bf16);
-        HRS_CHECK_HIP(hipMemcpyAsync(ns, c->shadow, (size_t)r_from * c->Dpad * esz, hipMemcpyDeviceToDevice, st));
-        if (ng) {
-            HRS_CHECK_HIP(hipMemcpyAsync(ng, c->group_pre, (size_t)(r_from / 32) * sizeof(float4), hipMemcpyDeviceToDevice, st));
-            HRS_CHECK_HIP(hipMemcpyAsync(ng + cap / 32 + 32, c->group_main, (size_t)(r_from / 32) * sizeof(float4), hipMemcpyDeviceToDevice, st));
+        hipError_t e = hipMemcpyAsync(ns, c->shadow, (size_t)r_from * c->Dpad * esz, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && ng) e = hipMemcpyAsync(ng, c->group_pre, (size_t)(r_from / 32) * sizeof(float4), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && ng)
+            e = hipMemcpyAsync(ng + cap / 32 + 32, c->group_main, (size_t)(r_from / 32) * sizeof(float4), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // the copies are done (and so is whatever read the old shadow on st)
+        if (e != hipSuccess) {
+            (void)hipFree(ns);
+            if (ng) (void)hipFree(ng);
+            hrs_set_error("hrs_corpus_append: copying the shadow into its larger allocation failed: %s", hipGetErrorString(e));
+            return HRS_ERR_HIP;
         }
-        HRS_CHECK_HIP(hipStreamSynchronize(st));  // the copies are done (and so is whatever read the old shadow on st)
         (void)hipFree(c->shadow);
         if (c->group_pre) (void)hipFree(c->group_pre);
         c->shadow = ns;
@@ -1000,6 +1015,9 @@ int hrs_append_shadow(hrs_ctx* ctx, hrs_corpus* c, const float* C, int64_t N_new
         c->group_main = ng ? ng + cap / 32 + 32 : nullptr;
         c->cap = cap;
     }
+    c->C = C;
+    c->N = N_new;
+    c->Npad = Npad_new;
     return shadow_fill(c, r_from, st);
 }
 

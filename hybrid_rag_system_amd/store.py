@@ -191,9 +191,18 @@ class Collection:
         """Under the lock: take in the rows other processes have committed since this object last looked, and cut
         off any uncommitted tail."""
         meta = self._read_meta()
-        if meta is None:
-            return
         d = self._dir()
+        if meta is None:
+            # Nothing has ever been committed: whatever the data files hold is the tail of a writer that died
+            # during the very first add (it had no commit record to be measured against).  Cut it off, or the next
+            # writer's rows would land behind it and be committed with lengths counted from offset 0.
+            if d and os.path.isdir(d) and not self.ids:
+                for name in ("rows.jsonl", "embeddings.f32"):
+                    path = os.path.join(d, name)
+                    if os.path.exists(path) and os.path.getsize(path) > 0:
+                        with open(path, "r+b") as f:
+                            f.truncate(0)
+            return
         if not self.ids:
             self.metadata = meta.get("metadata", self.metadata)
             self.space = meta.get("space", self.space)
@@ -483,15 +492,18 @@ class Collection:
         pitch = (n + 3) // 4 * 4
         cls = np.zeros((len(texts), pitch), np.uint8)
         levels = 1
+        most = max((len(list(kws)) for kws in keywords), default=0)
+        if most > 255:
+            raise ValueError(f"{most} keywords in one query: a row's match count is one byte (at most 255)")
+        if (most + 1) * k > 2048:  # before any pass over the corpus
+            raise ValueError(f"(keywords + 1) * n_results = {(most + 1) * k} candidates per query exceed 2048")
         for b, kws in enumerate(keywords):
-            kws = list(kws)[:255]
+            kws = list(kws)
             levels = max(levels, len(kws) + 1)
             if kws:
                 cls[b, :n] = np.fromiter((sum(1 for kw in kws if kw in d) for d in low), np.uint8, n)
         corpus = self._resident()
         keys = eng.score_topk_levels(corpus, q.contiguous(), k, levels, torch.from_numpy(cls).to(eng.device), space=self.space)
-        if levels * k > 2048:
-            raise ValueError(f"(keywords + 1) * n_results = {levels * k} candidates per query exceed 2048")
         merged = eng.merge_topk(keys.view(1, len(texts), levels * k))  # all classes, nearest first
         dist, rows = eng.unpack_keys(merged)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()

@@ -248,7 +248,8 @@ int hrs_postings_register_inverted(hrs_ctx* ctx, const int64_t* term_offs_dev, c
                                    int64_t N, hrs_inverted** out);
 int hrs_postings_release_inverted(hrs_ctx* ctx, hrs_inverted* p);
 /* counts_dev uint8 [B, row_pitch] (row_pitch >= N, a multiple of 4): counts_dev[b][r] = how many of query b's terms
- * (distinct, fewer than 256) occur in local row r -- the numerator of calculate_keyword_score for every row. */
+ * (distinct; only the first 255 terms of a query are counted, a count is one byte) occur in local row r -- the
+ * numerator of calculate_keyword_score for every row. */
 int hrs_match_counts(hrs_ctx* ctx, hrs_inverted* p, const int32_t* q_terms_dev, const int32_t* q_term_offs_dev, int B,
                      int64_t row_pitch, uint8_t* counts_dev, void* stream);
 /* keys_dev uint64 [B, levels, k]: for every query and every l < levels the exact top-k (as hrs_score_topk, exact

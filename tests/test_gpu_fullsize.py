@@ -76,3 +76,51 @@ def test_full_size_large_k_stays_on_the_matrix_cores(world, k, b):
     sel = torch.tensor([0, 1, 63, 64, 65, b - 1], device="cuda")
     _, _, k2 = eng.score_topk(corpus, qs[sel].contiguous(), k, mode="exact", want_keys=True)
     assert torch.equal(k1[sel], k2)
+
+
+def test_full_size_hybrid_step_counts_and_fusion(world):
+    """The whole step the benchmark times -- top-2n scan, keyword counts over the 9.6e8-entry synthetic postings,
+    fusion -- at full size: for every query the candidates' term matches are recounted by the oracle from the
+    candidates' own term lists, and order and fused scores must equal the oracle's fusion of the same (distance,
+    count) pairs bit for bit (scripts/chromadb_helper.py:296-325, 352-359); sampled queries' candidates equal the
+    fp64 streaming scan's."""
+    import bench
+    from hybrid_rag_system_amd.dist import HybridPipeline
+    from hybrid_rag_system_amd.engine import Engine
+    from oracle import search_oracle as so
+
+    eng, m, corpus, q, planted = world
+    n_keep, L = K // 2, bench.TERMS_PER_DOC
+    cdf = bench.zipf_cdf(bench.VOCAB, "cuda")
+    terms = eng.synth_postings(bench.SEED_POST, 0, N, cdf, L)
+    offs = torch.arange(N + 1, dtype=torch.int64, device="cuda") * L
+    post = eng.postings(offs, terms.reshape(-1))
+    q_terms, q_offs = bench.make_query_terms(B, "cuda")
+    eng2 = Engine(0)
+    pipe = HybridPipeline([eng, eng2], corpus, post, group=False)
+    for _ in range(3):
+        pipe.submit(q, q_terms, q_offs, n_keep)
+    out = pipe.drain()
+    torch.cuda.synchronize()
+    eng.set_peer(None)
+    eng2.set_peer(None)
+    rows = out["cand_rows"].cpu().numpy()
+    dist = out["cand_dist"].cpu().numpy()
+    assert (rows >= 0).all() and rows.shape == (B, K)
+    # the candidates' own term lists as a compact forward CSR: candidate (b, j) is row b * K + j of it
+    sub = terms[out["cand_rows"].reshape(-1)].cpu().numpy()
+    assert (np.diff(sub, axis=1) > 0).all()  # ascending, distinct terms per row, as the oracle's postings are
+    want_cnt = so.keyword_counts(np.arange(B * K + 1, dtype=np.int64) * L, sub.reshape(-1), q_offs.cpu().numpy(), q_terms.cpu().numpy(),
+                                 np.arange(B * K, dtype=np.int64).reshape(B, K))
+    assert np.array_equal(out["cand_counts"].cpu().numpy(), want_cnt)
+    assert want_cnt.max() >= 1  # Zipf terms: the popular ones do occur among the candidates
+    wc, wp, _, _ = so.fuse_sort(dist, want_cnt, np.diff(q_offs.cpu().numpy()), n_keep, 0.3)
+    assert np.array_equal(out["perm"].cpu().numpy(), wp)
+    assert np.array_equal(out["combined"].cpu().numpy().view(np.uint64), wc.view(np.uint64))
+    sel = torch.tensor([0, 1, 63, 64, 500, 1023], device="cuda")
+    xd, xr = eng.score_topk(corpus, q[sel].contiguous(), K, mode="exact")
+    assert torch.equal(xr, out["cand_rows"][sel]) and torch.equal(xd, out["cand_dist"][sel])
+    post.close()
+    eng2.close()
+    del terms, offs
+    torch.cuda.empty_cache()

@@ -403,6 +403,26 @@ def test_keyword_counts_fuse_merge(eng):
     post.close()
 
 
+def test_keyword_counts_with_negative_query_terms_and_ragged_rows(eng):
+    """Query terms may be any int32 (a term the vocabulary does not hold): lanes beyond the end of a row's term list
+    must not compare as a match for any of them."""
+    rng = np.random.default_rng(5)
+    n, B, c = 400, 9, 12
+    lens = rng.integers(0, 150, n)  # row lengths around and across the 64-term blocks, empty rows included
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    terms = np.concatenate([np.sort(rng.choice(1000, L, replace=False)) for L in lens]).astype(np.int32)
+    qt = [np.array(t, np.int32) for t in ([-2], [-1, -2, 0], [5, -2, 7], [], [0], [-2147483648, 2147483647], [3, 3], [-2, -2], [1, 2, 3, 4])]
+    qoffs = np.concatenate([[0], np.cumsum([len(t) for t in qt])]).astype(np.int32)
+    qterms = np.concatenate(qt).astype(np.int32)
+    rows = rng.integers(0, n, (B, c)).astype(np.int64)
+    want = so.keyword_counts(offs, terms, qoffs, qterms, rows)
+    assert want[0].max() == 0 and want[7].max() == 0
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
+    got = eng.keyword_counts(post, torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), torch.from_numpy(rows).cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+    post.close()
+
+
 def test_keyword_counts_and_fusion_reproduce_the_reference(eng):
     """hrs_keyword_counts + hrs_fuse_sort against the outputs of the reference's own hybrid_query
     (scripts/chromadb_helper.py:296-325, 352-359; tests/golden/make_fusion_goldens.py): order, fused scores

@@ -65,6 +65,25 @@ def test_tail_of_a_dead_writer_is_cut_off(tmp_path):
         Client(path).get_or_create_collection("crash")
 
 
+def test_a_writer_that_died_during_the_very_first_add_leaves_nothing_behind(tmp_path):
+    """No meta.json yet, but both data files already hold the dead writer's bytes: the next writer must not append
+    behind them (its commit record measures rows.jsonl from offset 0)."""
+    path = str(tmp_path / "data")
+    d = os.path.join(path, "first")
+    os.makedirs(d)
+    with open(os.path.join(d, "rows.jsonl"), "wb") as f:
+        f.write(b'{"id": "ghost", "document": "x", "metadata": {}}\n{"id": "torn')
+    with open(os.path.join(d, "embeddings.f32"), "wb") as f:
+        f.write(b"\x01" * 37)
+    col = Client(path).get_or_create_collection("first")
+    assert col.count() == 0
+    col.add(documents=["a", "b"], metadatas=[{}, {"k": 1}], ids=["a", "b"], embeddings=np.eye(2, 4, dtype=np.float32))
+    again = Client(path).get_or_create_collection("first")
+    assert again.ids == ["a", "b"] and again.documents == ["a", "b"]
+    assert np.array_equal(again._emb, np.eye(2, 4, dtype=np.float32))
+    assert os.path.getsize(os.path.join(d, "embeddings.f32")) == 2 * 4 * 4
+
+
 def test_an_open_collection_sees_rows_committed_by_others_before_it_adds(tmp_path):
     path = str(tmp_path / "data")
     a = Client(path).get_or_create_collection("two-views")
