@@ -310,7 +310,31 @@ struct GemmWsArgs {
     const float* ln_g;
     const float* ln_b;
     float eps;
+    // The block input x arrives WITHOUT its LayerNorm, as the rows z that k_gemm_down (or the embedding kernel) stored
+    // plus three partial (sum, sum of squares) per row: x = (z - mean) rstd g + b.
+    // EPI_QKV reads it as the GEMM operand, by linearity: x W^T = rstd (z (W g)^T - mean colsum(W g)) + W b, so W holds
+    // W g (bf16), csum its row sums and bias the original bias plus W b.  EPI_LN reads it as the residual and applies
+    // rin_g / rin_b element by element.
+    const float2* stats_in;  // [3][M]; EPI_QKV and EPI_LN always take their input this way
+    const float* csum;       // EPI_QKV with stats_in: [N]
+    const float* rin_g;      // EPI_LN with stats_in: [384]
+    const float* rin_b;
 };
+
+// LDS behind the three-tile ring of k_gemm_ws, in floats: bias | csum or ln_g | ln_b | rin_g | row partials of EPI_LN
+// [2][12 waves][32] float2 | (mean, rstd) of the rows of two tiles [2][64] float2 | the partial statistics of the next
+// tile's rows as the DMA delivers them [3 partials][sum, sum of squares][64]
+#define WS_OFF_PART 1536
+#define WS_OFF_MR (WS_OFF_PART + 2 * 12 * 32 * 2)
+#define WS_OFF_RAW (WS_OFF_MR + 2 * 64 * 2)
+#define WS_LDS_BYTES (3 * 64 * 768 + (WS_OFF_RAW + 6 * 64) * 4)
+
+// (mean, rstd) of a row from its three partial (sum, sum of squares), in a fixed order
+__device__ __forceinline__ float2 row_mean_rstd(float2 p0, float2 p1, float2 p2, float eps) {
+    const float s1 = (p0.x + p1.x) + p2.x, s2 = (p0.y + p1.y) + p2.y;
+    const float mean = s1 * (1.0f / ENC_H);
+    return make_float2(mean, rsqrtf(fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.f) + eps));
+}
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -369,21 +393,33 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     for (int s = 0; s < KS; ++s) wf[s] = *(const bf16x8*)(a.W + (size_t)(wfeat + i) * 384 + s * 16 + h * 8);
     // this workgroup's 384 biases live in LDS behind the tile ring (read back in the epilogue)
     float* bias_lds = (float*)(smem + 3 * TILE_BYTES);
-    if (threadIdx.x < 384) bias_lds[threadIdx.x] = a.bias[fg * 384 + threadIdx.x];
+    const bool fold = a.stats_in != nullptr;  // the input rows still need their LayerNorm (see GemmWsArgs)
+    // (EPI_LN with fold: the residual x = (z - mean) rstd g + b enters as bias + b here and as g (z - mean) rstd there)
+    if (threadIdx.x < 384) bias_lds[threadIdx.x] = a.bias[fg * 384 + threadIdx.x] + (EPI == EPI_LN && fold ? a.rin_b[threadIdx.x] : 0.f);
+    if (EPI == EPI_QKV && fold && threadIdx.x < 384) bias_lds[384 + threadIdx.x] = a.csum[fg * 384 + threadIdx.x];
     if (EPI == EPI_LN && threadIdx.x < 384) {
         bias_lds[384 + threadIdx.x] = a.ln_g[threadIdx.x];
         bias_lds[768 + threadIdx.x] = a.ln_b[threadIdx.x];
+        if (fold) bias_lds[1152 + threadIdx.x] = a.rin_g[threadIdx.x];
     }
-    float2* part = (float2*)(bias_lds + 1152);  // EPI_LN: [2][12 waves][32 tokens] (sum, sum of squares)
+    float2* part = (float2*)(bias_lds + WS_OFF_PART);  // EPI_LN: [2][12 waves][32 tokens] (sum, sum of squares)
+    float2* mr = (float2*)(bias_lds + WS_OFF_MR);      // fold: [2][64 tokens] (mean, rstd) of the input rows of two tiles
+    float* raw = bias_lds + WS_OFF_RAW;
     int pb = 0;
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s]));
 
     const int tiles = a.M / TR;
     const int t_begin = (int)((int64_t)tiles * slice / nslices);
     const int t_end = (int)((int64_t)tiles * (slice + 1) / nslices);
     const int count = t_end - t_begin;
+    // the first tile's row statistics the ordinary way (nothing of the ring is in flight yet); those of tile n + 1
+    // are fetched by wave 0 during tile n (see the loop)
+    if (fold && wv == 0 && count > 0) {
+        const size_t tok = (size_t)t_begin * TR + lane;
+        mr[lane] = row_mean_rstd(a.stats_in[tok], a.stats_in[(size_t)a.M + tok], a.stats_in[2 * (size_t)a.M + tok], a.eps);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[s]));
     if (count <= 0) return;
 
     int srcoff[IPW];
@@ -409,28 +445,53 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
     long long p_store = 0;
 #endif
     // epilogue of one 32-token subtile for the outputs without LayerNorm: 4 stores per lane
-    auto epilogue = [&](const f32x16& acc, const int tok0) __attribute__((always_inline)) {
+    auto epilogue = [&](const f32x16& acc, const int tok0, const int mr_half, const int mr_sub) __attribute__((always_inline)) {
         if (vwave) {
             // lane <-> feature d = i (+ head), registers <-> tokens tok0 + (r&3) + 8(r>>2) + 4h
             const int head = (wfeat - 768) >> 5;
             const int b = tok0 / a.S, sp0 = tok0 % a.S;  // 32-token tiles never straddle sequences (S % 32 == 0)
             const int kt = sp0 >> 5;
             __bf16* vb = a.vf + (((size_t)b * ENC_HEADS + head) * (a.S >> 5) + kt) * 1024 + (h * 32 + i) * 8;
+            const float bz = bias_lds[wv * 32 + i];
+            const float cs = fold ? bias_lds[384 + wv * 32 + i] : 0.f;
+            const float2* mrt = mr + mr_half * 64 + mr_sub * 32 + 4 * h;  // fold: (mean, rstd) of the tokens on the registers
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)(acc[8 * g2 + e] + bias_lds[wv * 32 + i]);
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[8 * g2 + e];
+                    if (fold) {
+                        const float2 t = mrt[(e & 3) + 8 * (2 * g2 + (e >> 2))];
+                        v = t.y * fmaf(-t.x, cs, v);
+                    }
+                    o[e] = (__bf16)(v + bz);
+                }
                 *(bf16x8*)(vb + g2 * 512) = o;
             }
         } else {
             const int token = tok0 + i;
             bf16x4 o[4];
+            float rm = 0.f, rs = 1.f;
+            if (EPI == EPI_QKV && fold) {
+                const float2 t = mr[mr_half * 64 + mr_sub * 32 + i];
+                rm = -t.x;
+                rs = t.y;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
-                float v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
-                float v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
+                float v0, v1, v2, v3;
+                if (EPI == EPI_QKV && fold) {
+                    const float4 cv = *(const float4*)(bias_lds + 384 + wv * 32 + 8 * g + 4 * h);
+                    v0 = fmaf(rs, fmaf(rm, cv.x, acc[4 * g + 0]), bv.x);
+                    v1 = fmaf(rs, fmaf(rm, cv.y, acc[4 * g + 1]), bv.y);
+                    v2 = fmaf(rs, fmaf(rm, cv.z, acc[4 * g + 2]), bv.z);
+                    v3 = fmaf(rs, fmaf(rm, cv.w, acc[4 * g + 3]), bv.w);
+                } else {
+                    v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
+                    v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
+                }
 #ifdef HRS_ENC_NOGELU
                 if (false) {
 #else
@@ -518,19 +579,41 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
 #endif
         int nb = buf + 2;
         if (nb >= 3) nb -= 3;
+        // fold: wave 0 fetches the partial row statistics of tile n + 1 into LDS (six 4-byte DMA pieces).  They are
+        // issued in front of this iteration's DMA, so the wait that ends the iteration -- the very wait the next one
+        // begins with -- covers them; wave 0 then turns them into (mean, rstd) in the other half of `mr`, which the
+        // waves read behind the next barrier.  Nobody else touches `raw`.
+        if (fold && wv == 0) {
+            const int tn = n + 1 < count ? n + 1 : count - 1;
+            const uint32_t rdst = lds_addr_of(raw);
+            // (one per-lane offset for all six; the partial and the component are steps of the scalar base)
+            const char* sbase = uniform_ptr((const char*)a.stats_in + (size_t)(t_begin + tn) * TR * 8);
+            const size_t sm = (size_t)a.M * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                glds4_asm(sbase + p * sm, lane * 8, rdst + (2 * p) * 256);
+                glds4_asm(sbase + p * sm + 4, lane * 8, rdst + (2 * p + 1) * 256);
+            }
+        }
+        auto stats_to_lds = [&]() __attribute__((always_inline)) {
+            mr[((n + 1) & 1) * 64 + lane] = row_mean_rstd(make_float2(raw[lane], raw[64 + lane]), make_float2(raw[128 + lane], raw[192 + lane]),
+                                                          make_float2(raw[256 + lane], raw[320 + lane]), a.eps);
+        };
         if (EPI != EPI_LN) issue(n + 2, nb);
         // EPI_LN: the residual rows come by asm loads so that their waits can be counted by hand next to
         // the DMA's (a load the compiler knows about would be waited for with everything older, DMA included)
         u32x2 rr[4];
-        int roff[4];
+        const int roff = (i * 384 + wv * 32 + 4 * h) * 2;  // this lane's residual pieces: + 16 bytes per piece
         const char* rbase = nullptr;
+        auto load_resid = [&](const char* rb) __attribute__((always_inline)) {
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rr[0]) : "v"(roff), "s"(rb) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(rr[1]) : "v"(roff), "s"(rb) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2 offset:32" : "=&v"(rr[2]) : "v"(roff), "s"(rb) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2 offset:48" : "=&v"(rr[3]) : "v"(roff), "s"(rb) : "memory");
+        };
         if (EPI == EPI_LN) {
             rbase = uniform_ptr((const char*)a.resid + (size_t)(t_begin + n) * TILE_BYTES);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                roff[g] = (i * 384 + wv * 32 + 8 * g + 4 * h) * 2;
-                asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rr[g]) : "v"(roff[g]), "s"(rbase) : "memory");
-            }
+            load_resid(rbase);
         }
         lds_cptr tb[8];
 #pragma unroll
@@ -543,7 +626,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            constexpr int PF = 4;
+            constexpr int PF = (EPI == EPI_GELU ? 4 : 3);
             bf16x8 av[KS];
 #pragma unroll
             for (int s = 0; s < PF; ++s)
@@ -579,25 +662,43 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             const int tok0 = (t_begin + n) * TR + sb * 32;
             if (EPI == EPI_LN) {
                 const int token = tok0 + i;
-                float v[16];
+                f32x16& v = acc;  // the sums replace the products where they stand
                 // residual of this subtile has landed; younger: nothing (subtile 0) or the DMA issued below (subtile 1)
-                if (sb == 0)
+                if (sb == 0) {
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3])::"memory");
-                else
+                    if (fold && wv == 0) stats_to_lds();  // (its DMA is covered by the wait above)
+                } else {
                     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]) : "n"(IPW) : "memory");
+                }
+                // the residual row still needs its LayerNorm: (mean, rstd) of this lane's token
+                float rm = 0.f, rs = 1.f;
+                if (fold) {
+                    const float2 t = mr[(n & 1) * 64 + sb * 32 + i];
+                    rm = t.x;
+                    rs = t.y;
+                }
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * g + 4 * h);
-                    v[4 * g + 0] = acc[4 * g + 0] + bv.x + __uint_as_float(rr[g].x << 16);
-                    v[4 * g + 1] = acc[4 * g + 1] + bv.y + __uint_as_float(rr[g].x & 0xffff0000u);
-                    v[4 * g + 2] = acc[4 * g + 2] + bv.z + __uint_as_float(rr[g].y << 16);
-                    v[4 * g + 3] = acc[4 * g + 3] + bv.w + __uint_as_float(rr[g].y & 0xffff0000u);
+                    float r[4] = {__uint_as_float(rr[g].x << 16), __uint_as_float(rr[g].x & 0xffff0000u),
+                                  __uint_as_float(rr[g].y << 16), __uint_as_float(rr[g].y & 0xffff0000u)};
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                    if (fold) {
+                        const float4 ig = *(const float4*)(bias_lds + 1152 + wv * 32 + 8 * g + 4 * h);
+                        const float gg[4] = {ig.x, ig.y, ig.z, ig.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf((r[e] - rm) * rs, gg[e], v[4 * g + e] + bb[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * g + e] = v[4 * g + e] + bb[e] + r[e];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         s1 += v[4 * g + e];
                         s2 = fmaf(v[4 * g + e], v[4 * g + e], s2);
                     }
+                    asm volatile("" : "+v"(s1), "+v"(s2));  // one piece at a time: keeps the LDS operands of the next from piling up
                 }
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
@@ -630,17 +731,21 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
                 if (sb == 0) {
                     // residual of the second subtile, then the tile two ahead (its buffer was freed by the barrier at the top)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rr[g]) : "v"(roff[g] + 32 * RB), "s"(rbase) : "memory");
+                    load_resid(rbase + 32 * RB);
                     issue(n + 2, nb);
                 }
             } else {
-                epilogue(acc, tok0);
+                epilogue(acc, tok0, n & 1, sb);
             }
 #ifdef HRS_ENC_PROF
             p_epi += wall_clock64() - pm1;
 #endif
+        }
+        if (EPI != EPI_LN && fold && wv == 0) {
+            // younger than the six pieces: this iteration's tile DMA and its stores
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
+            stats_to_lds();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in LDS before this wave joins the next barrier
         }
         buf = buf + 1 == 3 ? 0 : buf + 1;
     }
@@ -677,10 +782,12 @@ __global__ __launch_bounds__(768) void k_gemm_ws(GemmWsArgs a) {
 // 32-token x 512-deep stages (32 KB) through a 4-deep LDS ring by LDS-DMA, three stages in flight;
 // a token tile is finished every third stage.  Output: bias added, bf16, token-major.
 struct GemmDownArgs {
-    const __bf16* A;    // fragment-major [M / 32][96][64 lanes][8]: GemmWsArgs::frag_out
-    const __bf16* W;    // [384, 1536]
-    const float* bias;  // [384]
-    __bf16* C;          // [M, 384]
+    const __bf16* A;      // fragment-major [M / 32][96][64 lanes][8]: GemmWsArgs::frag_out
+    const __bf16* W;      // [384, 1536]
+    const float* bias;    // [384]
+    const __bf16* resid;  // [M, 384]: the block's input, added before the statistics are taken
+    __bf16* C;            // [M, 384]: A W^T + bias + resid, NOT normalised (its readers apply the LayerNorm)
+    float2* stats;        // [3][M]: per feature group, (sum, sum of squares) of a row's 128 stored (rounded) values
     int M;
 };
 
@@ -697,6 +804,10 @@ __device__ __forceinline__ void mfma_fence(f32x16& acc) {  // 8-pass MFMA result
     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
 }
 
+// The block's LayerNorm is not applied here: the row sums it needs span the three workgroups that share a token
+// slice.  Each writes the (sum, sum of squares) of its 128 features of every row -- taken from the bf16 values it
+// stores, so that the readers normalise exactly what they read -- and the readers (the next QKV projection, the
+// residual input of the next output projection, the pooling) finish the LayerNorm on the fly.
 __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
     constexpr int K = 1536, KC = 512, SPT = 3, KSS = 32, ROWB = KC * 2, STAGE = 32 * ROWB, IPW = 8, NBUF = 4;
     constexpr int NA = 56;  // weight fragments kept in AGPRs (232 of 256; 16 hold the accumulator)
@@ -711,9 +822,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
     bf16x8 wf[SPT * KSS];
 #pragma unroll
     for (int s = 0; s < SPT * KSS; ++s) wf[s] = *(const bf16x8*)(a.W + (size_t)(wfeat + i) * K + s * 16 + h * 8);
-    float bz[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = a.bias[wfeat + (r & 3) + 8 * (r >> 2) + 4 * h];
+    // behind the ring: this workgroup's 128 biases, the per-wave row sums of a finished tile [2][4 waves][32 rows], and
+    // per wave the 32 rows x 32 features of the residual that it adds (2 KB, by LDS-DMA: a load into registers would
+    // have to stay untouched across a stage, and the compiler is free to copy a register before its data has arrived)
+    float* bias_lds = (float*)(smem + NBUF * STAGE);
+    float2* part = (float2*)(bias_lds + 128);
+    char* resid_lds = (char*)(part + 2 * 4 * 32) + wv * 2048;
+    if (threadIdx.x < 128) bias_lds[threadIdx.x] = a.bias[fg * 128 + threadIdx.x];
 #pragma unroll
     for (int s = 0; s < SPT * KSS; ++s) {
         if (s < NA)
@@ -721,6 +836,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
         else
             asm volatile("" : "+v"(wf[s]));
     }
+    __syncthreads();
 
     const int tiles = a.M / 32;
     const int t_begin = (int)((int64_t)tiles * slice / nslices);
@@ -741,33 +857,55 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
 #pragma unroll
             for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
         };
+        // the row sums of tile t (complete in `part` behind a barrier) -> memory: every wave one store, 8 rows each
+        auto flush_stats = [&](int t) {
+            if (lane < 8) {
+                const int r = wv * 8 + lane;
+                const float2* pp = part + (t & 1) * 128 + r;
+                const float2 p0 = pp[0], p1 = pp[32], p2 = pp[64], p3 = pp[96];
+                a.stats[(size_t)fg * a.M + (size_t)(t_begin + t) * 32 + r] = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+            }
+        };
         typedef const __attribute__((address_space(3))) char* lds_cptr;
         typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
         const int fragoff = (int)lds0 + lane * 16;  // fragment s of a stage: + s * 1024, lane-linear
+        // residual DMA, two pieces per wave: lane l of piece j fetches the 16 bytes (8 features) l >> 4 of row 16 j + (l & 15)
+        // of this wave's 32 columns; a row's four pieces then sit 256 bytes apart and the epilogue's reads of 16
+        // consecutive rows fall on 16 different bank groups
+        const int roff = ((lane & 15) * ENC_H + wfeat + (lane >> 4) * 8) * 2;
+        const uint32_t resid_dst = lds_addr_of(resid_lds);
 
         issue(0);
         issue(1);
         issue(2);
-        f32x16 acc;
-        bool stored = false;
-        for (int g = 0; g < stages; ++g) {
-            const int kc = g % SPT;
-            // oldest first: DMA(g), DMA(g+1), DMA(g+2), then the 2 stores of a tile finished in stage g-1
-            if (stored)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW + 2) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(g + 3);
-            stored = false;
-            const lds_cptr tb = (lds_cptr)(size_t)(uint32_t)(fragoff + (g % NBUF) * STAGE);
-            if (kc == 0) {
+        // One iteration per token tile with its three stages written out: the accumulator lives inside the iteration
+        // (carried around the loop, the compiler moved it between two register ranges at every stage, and such a copy
+        // right behind the last MFMA of a stage reads results that are not interlocked for it).
+        const int ntiles = stages / SPT;
+        for (int tile = 0; tile < ntiles; ++tile) {
+            f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             constexpr int PF = 6;
-            auto run = [&](auto kc_tag) __attribute__((always_inline)) {
+            auto stage = [&](auto kc_tag) __attribute__((always_inline)) {
                 constexpr int KCI = decltype(kc_tag)::value;
+                const int g = tile * SPT + KCI;
+                // Vector-memory operations of a wave per tile, in order: stage 0: the statistics store of the tile before
+                // (1), DMA (8); stage 1: residual DMA (2), DMA (8); stage 2: DMA (8), output stores (2).  Each stage waits
+                // until its own DMA -- issued three stages earlier -- has landed and leaves everything younger in flight.
+                if (tile == 0)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KCI == 2 ? 2 * IPW + 2 : 2 * IPW) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KCI == 0 ? 2 * IPW + 2 + 2 : (KCI == 1 ? 2 * IPW + 2 + 1 : 2 * IPW + 2 + 1 + 2)) : "memory");
+                __builtin_amdgcn_s_barrier();
+                if (KCI == 0 && tile > 0) flush_stats(tile - 1);
+                if (KCI == 1) {
+                    const char* rbase = uniform_ptr((const char*)a.resid + (size_t)(t_begin + tile) * 32 * ENC_H * 2);
+                    glds16_asm(rbase, roff, resid_dst);
+                    glds16_asm(rbase + 16 * ENC_H * 2, roff, resid_dst + 1024);
+                }
+                issue(g + 3);
+                const lds_cptr tb = (lds_cptr)(size_t)(uint32_t)(fragoff + (g % NBUF) * STAGE);
                 bf16x8 av[KSS];
 #pragma unroll
                 for (int s = 0; s < PF; ++s) av[s] = *(lds_frag)(tb + s * 1024);
@@ -779,27 +917,42 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
                     else
                         mfma_wv(acc, wf[KCI * KSS + s], av[s]);
                 }
+                mfma_fence(acc);  // (every stage: nothing the compiler places behind it may meet an unfinished MFMA)
             };
-            if (kc == 0)
-                run(std::integral_constant<int, 0>{});
-            else if (kc == 1)
-                run(std::integral_constant<int, 1>{});
-            else {
-                run(std::integral_constant<int, 2>{});
-                mfma_fence(acc);
-                const int token = (t_begin + g / SPT) * 32 + i;
-                bf16x4 o[4];
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{});
+            // the residual rows have landed; younger than them: the DMA of this stage and of the one before
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+            const int token = (t_begin + tile) * 32 + i;
+            const char* rrow = resid_lds + (i >> 4) * 1024 + (i & 15) * 16 + h * 8;  // + 256 per 8-feature piece
+            bf16x4 o[4];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bv = *(const float4*)(bias_lds + wv * 32 + 8 * gq + 4 * h);
+                const u32x2 rr = *(const u32x2*)(rrow + gq * 256);
+                o[gq][0] = (__bf16)(acc[4 * gq + 0] + bv.x + __uint_as_float(rr.x << 16));
+                o[gq][1] = (__bf16)(acc[4 * gq + 1] + bv.y + __uint_as_float(rr.x & 0xffff0000u));
+                o[gq][2] = (__bf16)(acc[4 * gq + 2] + bv.z + __uint_as_float(rr.y << 16));
+                o[gq][3] = (__bf16)(acc[4 * gq + 3] + bv.w + __uint_as_float(rr.y & 0xffff0000u));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[gq][e] = (__bf16)(acc[4 * gq + e] + bz[4 * gq + e]);
+                for (int e = 0; e < 4; ++e) {
+                    const float r = (float)o[gq][e];
+                    s1 += r;
+                    s2 = fmaf(r, r, s2);
                 }
-                __bf16* dst = a.C + (size_t)token * ENC_H + wfeat;
-                *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
-                *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
-                stored = true;
             }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (h == 0) part[((tile & 1) * 4 + wv) * 32 + i] = make_float2(s1, s2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in LDS before this wave joins the next barrier
+            __bf16* dst = a.C + (size_t)token * ENC_H + wfeat;
+            *(u32x4*)(dst + 8 * h) = piece_exchange(o[0], o[1]);
+            *(u32x4*)(dst + 16 + 8 * h) = piece_exchange(o[2], o[3]);
         }
+        __syncthreads();
+        flush_stats(stages / SPT - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -940,92 +1093,61 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per token: 384 features = 6 per lane.
-__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, const float* __restrict__ word,
-                                                  const float* __restrict__ pos, const float* __restrict__ type0,
-                                                  const float* __restrict__ g, const float* __restrict__ bta, int M,
-                                                  int Mreal, int S, int vocab, float eps, __bf16* __restrict__ x) {
+// One wave per token: 384 features = 6 per lane.  The embedding LayerNorm is left to the readers of x (as the
+// block-output LayerNorm is, see k_gemm_down): the row goes out as the bf16 sum of its three embeddings, with the
+// (sum, sum of squares) of those rounded values as the first of its three partial statistics (the others zero).
+__global__ __launch_bounds__(256) void k_embed_sum(const int* __restrict__ ids, const float* __restrict__ word,
+                                                   const float* __restrict__ pos, const float* __restrict__ type0, int M,
+                                                   int Mreal, int S, int vocab, __bf16* __restrict__ x,
+                                                   float2* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
     int id = t < Mreal ? ids[t] : 0;
     if (id < 0 || id >= vocab) id = 0;
     const int sp = t % S;
-    float v[6];
-    float sum = 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int c = lane + 64 * j;
-        v[j] = word[(size_t)id * ENC_H + c] + pos[(size_t)sp * ENC_H + c] + type0[c];
-        sum += v[j];
+        const __bf16 o = (__bf16)(word[(size_t)id * ENC_H + c] + pos[(size_t)sp * ENC_H + c] + type0[c]);
+        x[(size_t)t * ENC_H + c] = o;
+        const float r = (float)o;
+        s1 += r;
+        s2 = fmaf(r, r, s2);
     }
-    const float mean = wave_sum(sum) * (1.0f / ENC_H);
-    float var = 0.f;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const float d = v[j] - mean;
-        var += d * d;
-    }
-    const float rstd = rsqrtf(wave_sum(var) * (1.0f / ENC_H) + eps);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int c = lane + 64 * j;
-        x[(size_t)t * ENC_H + c] = (__bf16)((v[j] - mean) * rstd * g[c] + bta[c]);
-    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane < 3) stats[(size_t)lane * M + t] = lane == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
 }
 
-// LayerNorm of bf16 rows: lanes 0..47 hold 8 features each (16-byte accesses).
-__global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ in, const __bf16* __restrict__ resid,
-                                                   const float* __restrict__ g, const float* __restrict__ bta, int M,
-                                                   float eps, __bf16* __restrict__ out) {
+// (sum, sum of squares) of bf16 rows, for the path whose down projection is the generic GEMM: one wave per row.
+__global__ __launch_bounds__(256) void k_row_stats(const __bf16* __restrict__ x, int M, float2* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
-    float v[8];
-    float sum = 0.f;
-    const bool on = lane < 48;
-    if (on) {
-        const bf16x8 r = *(const bf16x8*)(in + (size_t)t * ENC_H + lane * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)r[j];
-        if (resid) {
-            const bf16x8 r2 = *(const bf16x8*)(resid + (size_t)t * ENC_H + lane * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)r2[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += v[j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    }
-    const float mean = wave_sum(sum) * (1.0f / ENC_H);
-    float var = 0.f;
-    if (on) {
+    float s1 = 0.f, s2 = 0.f;
+    if (lane < 48) {
+        const bf16x8 r = *(const bf16x8*)(x + (size_t)t * ENC_H + lane * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float d = v[j] - mean;
-            var += d * d;
+            const float v = (float)r[j];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
         }
     }
-    const float rstd = rsqrtf(wave_sum(var) * (1.0f / ENC_H) + eps);
-    if (on) {
-        bf16x8 o;
-        const float4 g0 = *(const float4*)(g + lane * 8), g1 = *(const float4*)(g + lane * 8 + 4);
-        const float4 b0 = *(const float4*)(bta + lane * 8), b1 = *(const float4*)(bta + lane * 8 + 4);
-        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)((v[j] - mean) * rstd * gg[j] + bb[j]);
-        *(bf16x8*)(out + (size_t)t * ENC_H + lane * 8) = o;
-    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane < 3) stats[(size_t)lane * M + t] = lane == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
 }
 
-// Masked mean over the sequence + L2 normalisation. One block of 384 threads (6 waves) per sequence: wave w
-// sums the tokens w, w + 6, ... with 16-byte reads (lanes 0..47 hold 8 features each), the six partial rows
-// meet in LDS, then thread c owns feature c.
-__global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x, const int* __restrict__ lens, int S,
-                                                   float* __restrict__ out) {
+// The last block's LayerNorm, masked mean over the sequence, L2 normalisation.  One block of 384 threads (6 waves)
+// per sequence: wave w sums (z - mean) rstd over the tokens w, w + 6, ... with 16-byte reads (lanes 0..47 hold 8
+// features each), the six partial rows meet in LDS, then thread c owns feature c: the mean over the tokens of
+// LayerNorm(z) is g_c / len * that sum + b_c.
+__global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x, const float2* __restrict__ stats, int M,
+                                                   const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                   const int* __restrict__ lens, int S, float* __restrict__ out) {
     __shared__ float part[6][ENC_H];
     __shared__ float red[6];
     const int b = blockIdx.x, c = threadIdx.x;
@@ -1037,9 +1159,11 @@ __global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x,
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (lane < 48) {
         for (int t = wv; t < len; t += 6) {
-            const bf16x8 r = *(const bf16x8*)(x + ((size_t)b * S + t) * ENC_H + lane * 8);
+            const size_t tok = (size_t)b * S + t;
+            const bf16x8 r = *(const bf16x8*)(x + tok * ENC_H + lane * 8);
+            const float2 mr = row_mean_rstd(stats[tok], stats[(size_t)M + tok], stats[2 * (size_t)M + tok], eps);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)r[j];
+            for (int j = 0; j < 8; ++j) acc[j] += ((float)r[j] - mr.x) * mr.y;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) part[wv][lane * 8 + j] = acc[j];
@@ -1048,8 +1172,7 @@ __global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x,
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 6; ++w) s += part[w][c];
-    const float denom = len > 0 ? (float)len : 1e-9f;
-    const float mean = s / denom;
+    const float mean = len > 0 ? fmaf(g[c], s / (float)len, bta[c]) : 0.f;
     float ss = wave_sum(mean * mean);
     if (lane == 0) red[wv] = ss;
     __syncthreads();
@@ -1058,6 +1181,32 @@ __global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x,
     for (int j = 0; j < 6; ++j) tot += red[j];
     const float nrm = fmaxf(sqrtf(tot), 1e-12f);
     out[(size_t)b * ENC_H + c] = mean / nrm;
+}
+
+// W [N, 384] fp32, LayerNorm weights g / b of the rows W is applied to -> Wg = bf16(W g), csum = row sums of the
+// ROUNDED Wg (what the matrix cores will multiply the row mean with), bias_out = bias + W b.  One wave per row.
+__global__ __launch_bounds__(256) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ g,
+                                                 const float* __restrict__ b, const float* __restrict__ bias, int N,
+                                                 __bf16* __restrict__ Wg, float* __restrict__ csum, float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float cs = 0.f, wb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int k = lane + 64 * j;
+        const float w = W[(size_t)n * ENC_H + k];
+        const __bf16 o = (__bf16)(w * g[k]);
+        Wg[(size_t)n * ENC_H + k] = o;
+        cs += (float)o;
+        wb = fmaf(w, b[k], wb);
+    }
+    cs = wave_sum(cs);
+    wb = wave_sum(wb);
+    if (lane == 0) {
+        csum[n] = cs;
+        bias_out[n] = bias[n] + wb;
+    }
 }
 
 __global__ void k_to_bf16(const float* __restrict__ in, int64_t n, __bf16* __restrict__ out) {
@@ -1071,8 +1220,9 @@ struct hrs_encoder {
     // fp32 tables / vectors (owned copies)
     float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
     struct Layer {
-        __bf16 *wqkv = nullptr, *wo = nullptr, *wi = nullptr, *wd = nullptr;
-        float *bqkv = nullptr, *bo = nullptr, *bi = nullptr, *bd = nullptr;
+        __bf16 *wqkv = nullptr, *wo = nullptr, *wi = nullptr, *wd = nullptr;  // wqkv: W g of the LayerNorm in front of it
+        float *bqkv = nullptr, *bo = nullptr, *bi = nullptr, *bd = nullptr;   // bqkv: bias + W b of that LayerNorm
+        float* cqkv = nullptr;                                                // row sums of wqkv
         float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
     } layer[16];
     std::vector<void*> owned;
@@ -1133,10 +1283,17 @@ extern "C" int hrs_encoder_load(hrs_ctx* ctx, const hrs_encoder_config* cfg, con
         hrs_encoder::Layer& L = e->layer[l];
         TRY(dev_alloc(e, (void**)&L.wqkv, 3 * H * H * sizeof(__bf16)));
         TRY(dev_alloc(e, (void**)&L.bqkv, 3 * H * sizeof(float)));
-        for (int j = 0; j < 3; ++j) {
-            TRY(conv_bf16(e, L.wqkv + j * H * H, p[2 * j], H * H, st));
-            if (hipMemcpyAsync(L.bqkv + j * H, p[2 * j + 1], H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                hrs_set_error("hrs_encoder_load: bias copy failed");
+        TRY(dev_alloc(e, (void**)&L.cqkv, 3 * H * sizeof(float)));
+        {
+            // The LayerNorm in front of this block (the embedding's, or the block before's second) is folded into the
+            // projection that reads the block's input (see GemmWsArgs::stats_in).
+            const float* in_g = l == 0 ? w[3] : w[5 + 16 * (l - 1) + 14];
+            const float* in_b = l == 0 ? w[4] : w[5 + 16 * (l - 1) + 15];
+            for (int j = 0; j < 3; ++j)
+                hipLaunchKernelGGL(k_fold_ln, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, st, p[2 * j], in_g, in_b, p[2 * j + 1], (int)H,
+                                   L.wqkv + j * H * H, L.cqkv + j * H, L.bqkv + j * H);
+            if (hipGetLastError() != hipSuccess) {
+                hrs_set_error("hrs_encoder_load: folding the LayerNorm into the QKV weights failed");
                 rc = HRS_ERR_HIP;
                 goto fail;
             }
@@ -1194,7 +1351,7 @@ static int launch_gemm(hrs_ctx* ctx, const GemmArgs& g, hipStream_t st) {
 template <int EPI>
 static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
     static hrs_per_device_once attr;
-    const int lds = 3 * 64 * 768 + 384 * 4 + (EPI == EPI_LN ? 2 * 384 * 4 + 2 * 12 * 32 * 8 : 0);
+    const int lds = WS_LDS_BYTES;
     if (attr.need(ctx->device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_ws<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr.done(ctx->device);
@@ -1210,7 +1367,7 @@ static int launch_gemm_ws(hrs_ctx* ctx, const GemmWsArgs& g, hipStream_t st) {
 
 static int launch_gemm_down(hrs_ctx* ctx, const GemmDownArgs& g, hipStream_t st) {
     static hrs_per_device_once attr;
-    const int lds = 4 * 32 * 1024;
+    const int lds = 4 * 32 * 1024 + 128 * 4 + 2 * 4 * 32 * 8 + 4 * 2048;  // ring, biases, row sums, residual rows
     if (attr.need(ctx->device)) {
         HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_down, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr.done(ctx->device);
@@ -1259,29 +1416,37 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const size_t o_x = carve((size_t)M * H * 2), o_y = carve((size_t)M * H * 2), o_pre = carve((size_t)M * H * 2);
+    // x: a block's input / output rows WITHOUT their LayerNorm, st: their partial row statistics (see GemmWsArgs::stats_in)
+    const size_t o_x = carve((size_t)M * H * 2), o_y = carve((size_t)M * H * 2), o_st = carve((size_t)3 * M * sizeof(float2));
     const size_t o_ctx = carve((size_t)M * H * 2), o_q = carve((size_t)M * H * 2), o_k = carve((size_t)M * H * 2);
     const size_t o_v = carve((size_t)M * H * 2), o_h = carve((size_t)M * I * 2), o_len = carve((size_t)Bpad * 4);
     int rc = hrs_ws_reserve(ctx, &e->ws, off);
     if (rc) return rc;
     char* ws = (char*)e->ws.ptr;
-    __bf16 *x = (__bf16*)(ws + o_x), *y = (__bf16*)(ws + o_y), *pre = (__bf16*)(ws + o_pre), *cx = (__bf16*)(ws + o_ctx);
+    __bf16 *x = (__bf16*)(ws + o_x), *y = (__bf16*)(ws + o_y), *cx = (__bf16*)(ws + o_ctx);
     __bf16 *q = (__bf16*)(ws + o_q), *k = (__bf16*)(ws + o_k), *vf = (__bf16*)(ws + o_v), *hbuf = (__bf16*)(ws + o_h);
+    float2* stats = (float2*)(ws + o_st);
     int* lens = (int*)(ws + o_len);
     HRS_CHECK_HIP(hipMemsetAsync(lens, 0, (size_t)Bpad * 4, st));
     HRS_CHECK_HIP(hipMemcpyAsync(lens, lens_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_embed_ln, dim3((M + 3) / 4), dim3(256), 0, st, ids_dev, e->word, e->pos, e->type0, e->emb_g,
-                       e->emb_b, M, Mreal, S, e->cfg.vocab, e->cfg.eps, x);
+    hipLaunchKernelGGL(k_embed_sum, dim3((M + 3) / 4), dim3(256), 0, st, ids_dev, e->word, e->pos, e->type0, M, Mreal, S,
+                       e->cfg.vocab, x, stats);
     for (int l = 0; l < e->cfg.layers; ++l) {
         const hrs_encoder::Layer& L = e->layer[l];
+        // the LayerNorm that x still needs: the embedding's, or the second one of the block before
+        const float* in_g = l == 0 ? e->emb_g : e->layer[l - 1].ln2g;
+        const float* in_b = l == 0 ? e->emb_b : e->layer[l - 1].ln2b;
         GemmArgs g;
         GemmWsArgs gw;
         memset(&gw, 0, sizeof(gw));
         gw.M = M;
         gw.S = S;
+        gw.eps = e->cfg.eps;
         gw.A = x;
         gw.W = L.wqkv;
         gw.bias = L.bqkv;
+        gw.csum = L.cqkv;
+        gw.stats_in = stats;
         gw.N = 3 * H;
         gw.q = q;
         gw.k = k;
@@ -1299,13 +1464,16 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
         gw.A = cx;
         gw.W = L.wo;
         gw.bias = L.bo;
+        gw.csum = nullptr;
         gw.C = y;
         gw.N = H;
         gw.resid = x;
+        gw.rin_g = in_g;
+        gw.rin_b = in_b;
         gw.ln_g = L.ln1g;
         gw.ln_b = L.ln1b;
-        gw.eps = e->cfg.eps;
         if ((rc = launch_gemm_ws<EPI_LN>(ctx, gw, st))) return rc;  // attention output projection + residual + LayerNorm
+        gw.stats_in = nullptr;  // y is normalised
         gw.A = y;
         gw.W = L.wi;
         gw.bias = L.bi;
@@ -1318,15 +1486,16 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
             gd.A = hbuf;
             gd.W = L.wd;
             gd.bias = L.bd;
-            gd.C = pre;
+            gd.resid = y;
+            gd.C = x;
+            gd.stats = stats;
             gd.M = M;
             if ((rc = launch_gemm_down(ctx, gd, st))) return rc;
-            hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, y, L.ln2g, L.ln2b, M, e->cfg.eps, x);
         } else {
             memset(&g, 0, sizeof(g));
             g.M = M;
             g.S = S;
-            g.C = pre;
+            g.C = x;
             g.N = H;
             g.A = hbuf;
             g.W = L.wd;
@@ -1334,10 +1503,30 @@ extern "C" int hrs_encode(hrs_ctx* ctx, hrs_encoder* e, const int32_t* ids_dev, 
             g.resid = y;
             g.K = I;
             if ((rc = launch_gemm<EPI_RESID>(ctx, g, st))) return rc;
-            hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, pre, (const __bf16*)nullptr, L.ln2g, L.ln2b, M, e->cfg.eps, x);
+            hipLaunchKernelGGL(k_row_stats, dim3((M + 3) / 4), dim3(256), 0, st, x, M, stats);
         }
     }
-    hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(384), 0, st, x, lens, S, out_dev);
+#ifdef HRS_ENC_DEBUG
+    if (const char* dump = getenv("HRS_ENC_DUMP")) {  // debug builds only: the last block's output rows, their statistics, y
+        (void)hipStreamSynchronize(st);
+        std::vector<char> hb((size_t)M * H * 2), hy((size_t)M * H * 2), hs((size_t)3 * M * 8);
+        (void)hipMemcpy(hb.data(), x, hb.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hy.data(), y, hy.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hs.data(), stats, hs.size(), hipMemcpyDeviceToHost);
+        FILE* f = fopen(dump, "wb");
+        if (f) {
+            fwrite(&M, 4, 1, f);
+            fwrite(hb.data(), 1, hb.size(), f);
+            fwrite(hy.data(), 1, hy.size(), f);
+            fwrite(hs.data(), 1, hs.size(), f);
+            fclose(f);
+        }
+    }
+#endif
+    {
+        const hrs_encoder::Layer& Ll = e->layer[e->cfg.layers - 1];
+        hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(384), 0, st, x, stats, M, Ll.ln2g, Ll.ln2b, e->cfg.eps, lens, S, out_dev);
+    }
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }

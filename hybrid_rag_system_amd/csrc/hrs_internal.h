@@ -256,6 +256,15 @@ __device__ __forceinline__ void glds16_asm(const void* sbase, int voff, uint32_t
         : "v"(voff), "s"(sbase), "s"(lds_addr)
         : "memory");
 }
+// The same for 4 bytes per lane: LDS at lds_addr + lane*4.
+__device__ __forceinline__ void glds4_asm(const void* sbase, int voff, uint32_t lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_addr)
+        : "memory");
+}
 // A pointer the compiler can prove wave-uniform (it is, by construction, at every call site).
 __device__ __forceinline__ const char* uniform_ptr(const void* p) {
     const uint64_t v = (uint64_t)p;

@@ -14,10 +14,14 @@ CSRC = os.path.join(ROOT, "hybrid_rag_system_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+def _flags(src):
+    """The flags csrc/Makefile builds this file with (the encoder is built without SLP vectorisation)."""
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"] + (["-fno-slp-vectorize"] if src == "hrs_encoder.hip" else [])
+
+
 def _metadata(src, tmp_path):
     out = tmp_path / (src + ".s")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
-                           "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC] + _flags(src) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
     kernels, cur = {}, {}
     for line in out.read_text().splitlines():
         m = re.match(r"\s+\.(name|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|vgpr_count):\s+(\S+)", line)
@@ -45,8 +49,7 @@ def test_asm_mfma_kernels_do_not_spill(src, needle, tmp_path):
 def _kernel_bodies(src, tmp_path):
     out = tmp_path / (src + ".s")
     if not out.exists():
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
-                               "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
+        subprocess.check_call([HIPCC] + _flags(src) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
     bodies, name, cur = {}, None, []
     for line in out.read_text().splitlines():
         m = re.match(r"^(_Z\w+):", line)
@@ -148,3 +151,57 @@ def test_plain_exact_scan_keeps_its_dma_ring_in_flight(tmp_path):
             assert not any(b.startswith("s_waitcnt") and "vmcnt(0)" in b for b in before), (name, before)
             checked += 1
     assert checked >= 12
+
+
+def _vregs(text):
+    regs = set()
+    for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(lo), int(hi) + 1))
+    regs.update(int(n) for n in re.findall(r"\bv(\d+)\b", text))
+    return regs
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
+def test_vector_load_destinations_rest_until_a_wait(tmp_path):
+    """The encoder's GEMMs load residual rows by hand-written global loads whose wait is a separate statement further
+    down (counted with the LDS-DMA's).  Until that wait the destination registers hold stale values, and nothing stops
+    the compiler from copying them elsewhere in between (it did, in a kernel whose load and wait were a loop iteration
+    apart: a few rows of the block output were then slightly wrong).  In the generated code of every encoder kernel no
+    instruction may read the destination of a vector load before the next wait on vmcnt."""
+    loads = 0
+    for name, body in _kernel_bodies("hrs_encoder.hip", tmp_path).items():
+        pending = {}
+        for idx, ins in enumerate(body):
+            op = ins.split()[0]
+            if op == "s_waitcnt" and "vmcnt" in ins:
+                pending = {}
+                continue
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pending = {}
+                continue
+            if op.startswith(("global_load_dword", "global_load_ushort", "global_load_ubyte", "buffer_load_dword", "scratch_load")) and "lds" not in op:
+                parts = ins.split(",")
+                dst = _vregs(parts[0])
+                src = _vregs(",".join(parts[1:]))
+                assert not (src & set(pending)), (name, idx, ins, "address from a pending destination")
+                for r in dst:
+                    pending[r] = idx
+                loads += 1
+                continue
+            if op.startswith("global_load_lds") or op.startswith("global_store") or op.startswith("s_") or op.startswith("ds_read"):
+                used = _vregs(",".join(ins.split(",")[1:])) if op.startswith("ds_read") else _vregs(ins)
+            else:
+                used = _vregs(",".join(ins.split(",")[1:]))  # sources only: overwriting a dead destination is harmless
+            hit = used & set(pending)
+            assert not hit, (name, idx, ins, sorted(hit), body[pending[min(hit)]])
+    assert loads > 0
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
+def test_encoder_gemms_with_counted_waits_do_not_spill(tmp_path):
+    """A spill is a scratch store and, worse, a scratch load inside the loop: both count in vmcnt, and the kernels
+    that retire their LDS-DMA with counted waits would then wait for the wrong operations."""
+    ks = {n: k for n, k in _metadata("hrs_encoder.hip", tmp_path).items() if "k_gemm_ws" in n or "k_gemm_down" in n}
+    assert len(ks) >= 4
+    for name, k in ks.items():
+        assert int(k["vgpr_spill_count"]) == 0 and int(k["private_segment_fixed_size"]) == 0, (name, k)
