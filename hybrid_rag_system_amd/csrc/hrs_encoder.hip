@@ -300,7 +300,7 @@ struct GemmWsArgs {
     // each of 32 rows (a third of this kernel's time went into the 25 M 32-byte write requests of the row-major form),
     // the consumer's LDS-DMA copies consecutive bytes and its fragment reads are lane-linear.
     int frag_out;
-    __bf16* q;
+    __bf16* q;   // EPI_QKV: Q (pre-scaled), K and V all in MFMA operand order: [B][heads][S/32][2][64 lanes][8]
     __bf16* k;
     __bf16* vf;
     int M, N, S;
@@ -322,12 +322,12 @@ struct GemmWsArgs {
 };
 
 // LDS behind the three-tile ring of k_gemm_ws, in floats: bias | csum or ln_g | ln_b | rin_g | row partials of EPI_LN
-// [2][12 waves][32] float2 | (mean, rstd) of the rows of two tiles [2][64] float2 | the partial statistics of the next
-// tile's rows as the DMA delivers them [3 partials][sum, sum of squares][64]
+// [2][12 waves][32] float2 | (mean, rstd) of the rows of two tiles [2][64] float2 | per wave 64 floats: the partial
+// statistics of eight rows of the next tile as the wave's DMA piece delivers them [3 partials][sum, sum of squares][8]
 #define WS_OFF_PART 1536
 #define WS_OFF_MR (WS_OFF_PART + 2 * 12 * 32 * 2)
 #define WS_OFF_RAW (WS_OFF_MR + 2 * 64 * 2)
-#define WS_LDS_BYTES (3 * 64 * 768 + (WS_OFF_RAW + 6 * 64) * 4)
+#define WS_LDS_BYTES (3 * 64 * 768 + (WS_OFF_RAW + 12 * 64) * 4)
 
 // (mean, rstd) of a row from its three partial (sum, sum of squares), in a fixed order
 __device__ __forceinline__ float2 row_mean_rstd(float2 p0, float2 p1, float2 p2, float eps) {
@@ -520,19 +520,21 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 o[g][3] = (__bf16)v3;
             }
             // lower lane: pieces 0 and 2, upper lane: pieces 1 and 3 (features 8 * piece .. + 7 of this wave's 32)
-            __bf16* dst;
-            if (EPI == EPI_QKV) {
-                const int b = token / a.S, sp = token % a.S;
-                dst = (fg == 0 ? a.q : a.k) + (((size_t)b * ENC_HEADS + wv) * a.S + sp) * ENC_DH;  // this wave's 32 features are head wv
-            } else {
-                dst = a.C + (size_t)token * a.N + wfeat;
-            }
+            __bf16* dst = a.C + (size_t)token * a.N + wfeat;
 #ifdef HRS_ENC_NOSTORE
             const u32x4 e0 = piece_exchange(o[0], o[1]), e1 = piece_exchange(o[2], o[3]);
             // (never taken, but every value stays live: an ablation must not let the compiler drop the arithmetic)
             if ((e0.x ^ e0.y ^ e0.z ^ e0.w ^ e1.x ^ e1.y ^ e1.z ^ e1.w) == 0x12345678u) *(u32x4*)(dst + 8 * h) = e0;
 #else
-            if (EPI == EPI_GELU && a.frag_out) {
+            if (EPI == EPI_QKV) {
+                // Q and K leave as the attention kernel's MFMA operands: this wave's 32 features are head wv, two 16-deep
+                // k-steps = the two exchanged registers, so a store writes 1 KB of consecutive bytes
+                // [sequence][head][32-token tile][k-step][64 lanes][8] (32-token tiles never straddle sequences)
+                const int b = tok0 / a.S, qt = (tok0 % a.S) >> 5;
+                __bf16* fb = (fg == 0 ? a.q : a.k) + ((((size_t)b * ENC_HEADS + wv) * (a.S >> 5) + qt) * 128 + lane) * 8;
+                *(u32x4*)fb = piece_exchange(o[0], o[1]);
+                *(u32x4*)(fb + 512) = piece_exchange(o[2], o[3]);
+            } else if (EPI == EPI_GELU && a.frag_out) {
                 // this wave's features are two 16-feature k-steps of the consumer: two consecutive 1 KB blocks
                 __bf16* fb = a.C + (((size_t)(tok0 >> 5) * (a.N >> 4) + (wfeat >> 4)) * 64 + lane) * 8;
 #ifdef HRS_ENC_PROF
@@ -579,31 +581,39 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
 #endif
         int nb = buf + 2;
         if (nb >= 3) nb -= 3;
-        // fold: wave 0 fetches the partial row statistics of tile n + 1 into LDS (six 4-byte DMA pieces).  They are
-        // issued in front of this iteration's DMA, so the wait that ends the iteration -- the very wait the next one
-        // begins with -- covers them; wave 0 then turns them into (mean, rstd) in the other half of `mr`, which the
-        // waves read behind the next barrier.  Nobody else touches `raw`.
-        if (fold && wv == 0) {
+        // fold: the partial row statistics of tile n + 1 come into LDS by one 4-byte DMA piece per wave: waves 0..7 fetch
+        // the six values of eight rows each (lane l: row l & 7, value l >> 3; waves 8..11 repeat wave 7's piece into an
+        // area of their own, so that every wave counts the same operations).  The piece is issued in front of this
+        // iteration's tile DMA, so the wait that ends the iteration -- the very wait the next one begins with -- covers
+        // it; the wave then turns its eight rows into (mean, rstd) in the other half of `mr`, which all waves read
+        // behind the next barrier.  A wave's part of `raw` is touched by that wave alone.
+        float* raw_w = raw + wv * 64;
+        if (fold) {
             const int tn = n + 1 < count ? n + 1 : count - 1;
-            const uint32_t rdst = lds_addr_of(raw);
-            // (one per-lane offset for all six; the partial and the component are steps of the scalar base)
-            const char* sbase = uniform_ptr((const char*)a.stats_in + (size_t)(t_begin + tn) * TR * 8);
-            const size_t sm = (size_t)a.M * 8;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                glds4_asm(sbase + p * sm, lane * 8, rdst + (2 * p) * 256);
-                glds4_asm(sbase + p * sm + 4, lane * 8, rdst + (2 * p + 1) * 256);
-            }
+            const int sw = wv < 8 ? wv : 7;
+            const char* sbase = uniform_ptr((const char*)a.stats_in + ((size_t)(t_begin + tn) * TR + sw * 8) * 8);
+            int ll = lane;
+            asm volatile("" : "+v"(ll));  // (the offset is recomputed here each time rather than held in a register across the loop)
+            const int sp = ll < 48 ? ll >> 4 : 2;
+            glds4_asm(sbase, (sp * a.M + (ll & 7)) * 8 + ((ll >> 3) & 1) * 4, lds_addr_of(raw_w));
         }
         auto stats_to_lds = [&]() __attribute__((always_inline)) {
-            mr[((n + 1) & 1) * 64 + lane] = row_mean_rstd(make_float2(raw[lane], raw[64 + lane]), make_float2(raw[128 + lane], raw[192 + lane]),
-                                                          make_float2(raw[256 + lane], raw[320 + lane]), a.eps);
+            int ll = lane;
+            asm volatile("" : "+v"(ll));  // (addresses recomputed here, not held across the loop)
+            if (wv < 8 && ll < 8)
+                mr[((n + 1) & 1) * 64 + wv * 8 + ll] = row_mean_rstd(make_float2(raw_w[ll], raw_w[8 + ll]), make_float2(raw_w[16 + ll], raw_w[24 + ll]),
+                                                                     make_float2(raw_w[32 + ll], raw_w[40 + ll]), a.eps);
         };
         if (EPI != EPI_LN) issue(n + 2, nb);
         // EPI_LN: the residual rows come by asm loads so that their waits can be counted by hand next to
         // the DMA's (a load the compiler knows about would be waited for with everything older, DMA included)
         u32x2 rr[4];
-        const int roff = (i * 384 + wv * 32 + 4 * h) * 2;  // this lane's residual pieces: + 16 bytes per piece
+        int roff = 0;  // this lane's residual pieces: + 16 bytes per piece
+        if (EPI == EPI_LN) {
+            int ll = lane;
+            asm volatile("" : "+v"(ll));  // (recomputed per tile, see above)
+            roff = ((ll & 31) * 384 + wv * 32 + 4 * (ll >> 5)) * 2;
+        }
         const char* rbase = nullptr;
         auto load_resid = [&](const char* rb) __attribute__((always_inline)) {
             asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rr[0]) : "v"(roff), "s"(rb) : "memory");
@@ -626,7 +636,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            constexpr int PF = (EPI == EPI_GELU ? 4 : 3);
+            constexpr int PF = (EPI == EPI_LN ? 2 : 4);
             bf16x8 av[KS];
 #pragma unroll
             for (int s = 0; s < PF; ++s)
@@ -666,7 +676,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 // residual of this subtile has landed; younger: nothing (subtile 0) or the DMA issued below (subtile 1)
                 if (sb == 0) {
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3])::"memory");
-                    if (fold && wv == 0) stats_to_lds();  // (its DMA is covered by the wait above)
+                    if (fold) stats_to_lds();  // (its DMA piece is covered by the wait above)
                 } else {
                     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]) : "n"(IPW) : "memory");
                 }
@@ -741,8 +751,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             p_epi += wall_clock64() - pm1;
 #endif
         }
-        if (EPI != EPI_LN && fold && wv == 0) {
-            // younger than the six pieces: this iteration's tile DMA and its stores
+        if (EPI != EPI_LN && fold) {
+            // younger than the statistics piece: this iteration's tile DMA and its stores
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW + NST) : "memory");
             stats_to_lds();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in LDS before this wave joins the next barrier
@@ -965,8 +975,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
 // register order, which is the order V was stored in by the QKV epilogue), so the query is still on the
 // lane in the output, 1/l needs no shuffle and a context row leaves as two 16-byte stores per lane.
 struct AttnArgs {
-    const __bf16* q;   // [B][heads][S][32], scaled by log2(e)/sqrt(32)
-    const __bf16* k;   // [B][heads][S][32]
+    const __bf16* q;   // [B][heads][S/32][2][64][8] (MFMA operand order), scaled by log2(e)/sqrt(32)
+    const __bf16* k;   // the same order
     const __bf16* vf;  // [B][heads][S/32][2][64][8]
     const int* lens;   // [B]
     __bf16* ctx;       // [B*S][384]
@@ -978,9 +988,8 @@ struct AttnArgs {
 // copies every score tile out and every initial value in, 26 register moves per MFMA here).
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
-    // K (swizzled: 16-byte piece p of key row r at p ^ ((r >> 2) & 3), so that the 16 rows a
-    // ds_read_b128 lane group touches fall on 16 different bank groups) and V (already in fragment
-    // order) of this (sequence, head), shared by the four waves and by both passes
+    // K and V of this (sequence, head), both stored by the QKV projection in the order the MFMAs take them
+    // (fragment reads are lane-linear), shared by the four waves and by both passes
     __shared__ __attribute__((aligned(16))) char lds[2 * NKT * 32 * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -996,14 +1005,12 @@ __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
     const char* vb = (const char*)(a.vf + (size_t)bh * S * ENC_DH);
     char* klds = lds;
     char* vlds = lds + NKT * 32 * 64;
-    for (int pc = tid; pc < nkt * 128; pc += 256) {  // 16-byte pieces: 4 per key row
-        const int r = pc >> 2, p = pc & 3;
-        *(uint4*)(klds + r * 64 + ((p ^ ((r >> 2) & 3)) << 4)) = *(const uint4*)(kb + pc * 16);
+    for (int pc = tid; pc < nkt * 128; pc += 256) {  // 16-byte pieces, both already in fragment order: a straight copy
+        *(uint4*)(klds + pc * 16) = *(const uint4*)(kb + pc * 16);
         *(uint4*)(vlds + pc * 16) = *(const uint4*)(vb + pc * 16);
     }
     __syncthreads();
-    const int koff0 = i * 64 + (((0 + h) ^ ((i >> 2) & 3)) << 4);  // k-step 0 wants piece h, k-step 1 piece 2 + h
-    const int koff1 = i * 64 + (((2 + h) ^ ((i >> 2) & 3)) << 4);
+    const int koff0 = lane * 16, koff1 = 1024 + lane * 16;  // the two k-steps of a key tile: lane-linear, conflict-free
 
     for (int qt = wv; qt < NKT; qt += 4) {
         // the key masks of a partial tile are recomputed where they are used: hoisted out of this loop they
@@ -1011,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
         asm volatile("" : "+s"(len));
         bf16x8 qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + ((qt * 32 + i) * ENC_DH + ks * 16 + h * 8) * 2);
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + ((qt * 2 + ks) * 64 + lane) * 16);
         // pass 1: row maximum.  Scores are recomputed in pass 2 (two MFMAs per tile) instead of keeping
         // the 256-wide row in registers, which would leave one wave per SIMD and no latency hiding.
         float m = -1e30f;
