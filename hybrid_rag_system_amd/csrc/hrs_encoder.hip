@@ -329,11 +329,13 @@ struct GemmWsArgs {
 #define WS_OFF_RAW (WS_OFF_MR + 2 * 64 * 2)
 #define WS_LDS_BYTES (3 * 64 * 768 + (WS_OFF_RAW + 12 * 64) * 4)
 
-// (mean, rstd) of a row from its three partial (sum, sum of squares), in a fixed order
+// A row's normalisation (z - mean) rstd as z * A + B: (A, B) = (rstd, -mean rstd) from its three partial (sum, sum of
+// squares), added in a fixed order
 __device__ __forceinline__ float2 row_mean_rstd(float2 p0, float2 p1, float2 p2, float eps) {
     const float s1 = (p0.x + p1.x) + p2.x, s2 = (p0.y + p1.y) + p2.y;
     const float mean = s1 * (1.0f / ENC_H);
-    return make_float2(mean, rsqrtf(fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.f) + eps));
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.f) + eps);
+    return make_float2(rstd, -mean * rstd);
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -434,8 +436,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
         if (n >= count) n = count - 1;
         const char* base = uniform_ptr((const char*)a.A + (size_t)(t_begin + n) * TILE_BYTES);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + wv * (IPW * 1024));
-#pragma unroll
-        for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+        glds16_run_asm<IPW>(base, srcoff, dst);
     };
     typedef const __attribute__((address_space(3))) char* lds_cptr;
     const int rowoff = (int)lds0 + i * RB;
@@ -454,29 +455,35 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
             __bf16* vb = a.vf + (((size_t)b * ENC_HEADS + head) * (a.S >> 5) + kt) * 1024 + (h * 32 + i) * 8;
             const float bz = bias_lds[wv * 32 + i];
             const float cs = fold ? bias_lds[384 + wv * 32 + i] : 0.f;
-            const float2* mrt = mr + mr_half * 64 + mr_sub * 32 + 4 * h;  // fold: (mean, rstd) of the tokens on the registers
+            // fold: (A, B) of the tokens on the registers, four consecutive tokens = two 16-byte reads (the same address
+            // in every lane of a half wave); value = A acc + (B cs + bias)
+            const float4* mrt = (const float4*)(mr + mr_half * 64 + mr_sub * 32 + 4 * h);
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = acc[8 * g2 + e];
+                for (int eh = 0; eh < 2; ++eh) {
+                    float4 ab0 = make_float4(1.f, 0.f, 1.f, 0.f), ab1 = ab0;
                     if (fold) {
-                        const float2 t = mrt[(e & 3) + 8 * (2 * g2 + (e >> 2))];
-                        v = t.y * fmaf(-t.x, cs, v);
+                        ab0 = mrt[4 * (2 * g2 + eh)];
+                        ab1 = mrt[4 * (2 * g2 + eh) + 1];
                     }
-                    o[e] = (__bf16)(v + bz);
+                    const int r0 = 8 * g2 + 4 * eh;
+                    o[4 * eh + 0] = (__bf16)fmaf(ab0.x, acc[r0 + 0], fmaf(ab0.y, cs, bz));
+                    o[4 * eh + 1] = (__bf16)fmaf(ab0.z, acc[r0 + 1], fmaf(ab0.w, cs, bz));
+                    o[4 * eh + 2] = (__bf16)fmaf(ab1.x, acc[r0 + 2], fmaf(ab1.y, cs, bz));
+                    o[4 * eh + 3] = (__bf16)fmaf(ab1.z, acc[r0 + 3], fmaf(ab1.w, cs, bz));
                 }
                 *(bf16x8*)(vb + g2 * 512) = o;
             }
         } else {
             const int token = tok0 + i;
             bf16x4 o[4];
-            float rm = 0.f, rs = 1.f;
+            float rs = 1.f, rb = 0.f;  // fold: value = A acc + (B colsum + bias) with this lane's token's (A, B)
             if (EPI == EPI_QKV && fold) {
                 const float2 t = mr[mr_half * 64 + mr_sub * 32 + i];
-                rm = -t.x;
-                rs = t.y;
+                rs = t.x;
+                rb = t.y;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -484,10 +491,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 float v0, v1, v2, v3;
                 if (EPI == EPI_QKV && fold) {
                     const float4 cv = *(const float4*)(bias_lds + 384 + wv * 32 + 8 * g + 4 * h);
-                    v0 = fmaf(rs, fmaf(rm, cv.x, acc[4 * g + 0]), bv.x);
-                    v1 = fmaf(rs, fmaf(rm, cv.y, acc[4 * g + 1]), bv.y);
-                    v2 = fmaf(rs, fmaf(rm, cv.z, acc[4 * g + 2]), bv.z);
-                    v3 = fmaf(rs, fmaf(rm, cv.w, acc[4 * g + 3]), bv.w);
+                    v0 = fmaf(rs, acc[4 * g + 0], fmaf(rb, cv.x, bv.x));
+                    v1 = fmaf(rs, acc[4 * g + 1], fmaf(rb, cv.y, bv.y));
+                    v2 = fmaf(rs, acc[4 * g + 2], fmaf(rb, cv.z, bv.z));
+                    v3 = fmaf(rs, acc[4 * g + 3], fmaf(rb, cv.w, bv.w));
                 } else {
                     v0 = acc[4 * g + 0] + bv.x, v1 = acc[4 * g + 1] + bv.y;
                     v2 = acc[4 * g + 2] + bv.z, v3 = acc[4 * g + 3] + bv.w;
@@ -680,12 +687,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                 } else {
                     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]) : "n"(IPW) : "memory");
                 }
-                // the residual row still needs its LayerNorm: (mean, rstd) of this lane's token
-                float rm = 0.f, rs = 1.f;
+                // the residual row still needs its LayerNorm: (A, B) of this lane's token
+                float rs = 1.f, rb = 0.f;
                 if (fold) {
                     const float2 t = mr[(n & 1) * 64 + sb * 32 + i];
-                    rm = t.x;
-                    rs = t.y;
+                    rs = t.x;
+                    rb = t.y;
                 }
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -698,7 +705,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a) {
                         const float4 ig = *(const float4*)(bias_lds + 1152 + wv * 32 + 8 * g + 4 * h);
                         const float gg[4] = {ig.x, ig.y, ig.z, ig.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf((r[e] - rm) * rs, gg[e], v[4 * g + e] + bb[e]);
+                        for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(fmaf(r[e], rs, rb), gg[e], v[4 * g + e] + bb[e]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[4 * g + e] = v[4 * g + e] + bb[e] + r[e];
@@ -864,8 +871,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_down(GemmDownArgs a) {
             const int t = t_begin + g / SPT, kc = g % SPT;
             const char* base = uniform_ptr((const char*)a.A + ((size_t)t * (K / 16) + kc * KSS) * 1024);
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(g % NBUF) * STAGE + wv * (IPW * 1024));
-#pragma unroll
-            for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+            glds16_run_asm<IPW>(base, srcoff, dst);
         };
         // the row sums of tile t (complete in `part` behind a barrier) -> memory: every wave one store, 8 rows each
         auto flush_stats = [&](int t) {
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(384) void k_pool_norm(const __bf16* __restrict__ x,
             const bf16x8 r = *(const bf16x8*)(x + tok * ENC_H + lane * 8);
             const float2 mr = row_mean_rstd(stats[tok], stats[(size_t)M + tok], stats[2 * (size_t)M + tok], eps);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += ((float)r[j] - mr.x) * mr.y;
+            for (int j = 0; j < 8; ++j) acc[j] += fmaf((float)r[j], mr.x, mr.y);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) part[wv][lane * 8 + j] = acc[j];

@@ -256,6 +256,39 @@ __device__ __forceinline__ void glds16_asm(const void* sbase, int voff, uint32_t
         : "v"(voff), "s"(sbase), "s"(lds_addr)
         : "memory");
 }
+// N consecutive 1 KB pieces in one statement: piece j from (sbase + voff[j]) to lds_addr + j * 1024.  M0 is saved and
+// restored once and stepped between the pieces (three scalar instructions per piece instead of six: with one wave per
+// SIMD the DMA's issue is serial with the wave's MFMAs).
+template <int N>
+__device__ __forceinline__ void glds16_run_asm(const void* sbase, const int (&voff)[N], uint32_t lds_addr) {
+    static_assert(N == 4 || N == 8, "written out for 4 and 8 pieces");
+    unsigned keep;
+    if constexpr (N == 8) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %9\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %9\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]), "s"(sbase), "s"(lds_addr)
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds_addr)
+            : "memory", "scc");
+    }
+}
 // The same for 4 bytes per lane: LDS at lds_addr + lane*4.
 __device__ __forceinline__ void glds4_asm(const void* sbase, int voff, uint32_t lds_addr) {
     unsigned keep;
