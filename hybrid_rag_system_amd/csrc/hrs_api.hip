@@ -104,6 +104,7 @@ extern "C" int hrs_ctx_create(int device, hrs_ctx** out) {
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : HRS_NUM_CU;
     c->scan_qt1 = getenv("HRS_SCAN_QT1") != nullptr;
+    c->scan_shape32 = getenv("HRS_SCAN_SHAPE32") != nullptr;
     hipError_t e = hipMalloc((void**)&c->stats_dev, 16 * sizeof(int64_t));
     if (e != hipSuccess) {
         delete c;

@@ -57,6 +57,7 @@ struct hrs_ctx {
     int device = 0;
     int num_cu = HRS_NUM_CU;
     bool scan_qt1 = false;     // HRS_SCAN_QT1 in the environment at creation: one query tile per wave (tuning switch)
+    bool scan_shape32 = false; // HRS_SCAN_SHAPE32: the int8 main pass on the 32 x 32 x 32 MFMA shape (tuning switch)
     hrs_workspace ws_partial;  // exact scan: per (query, workgroup) top-k keys, and merge ping-pong
     hrs_workspace ws_mfma;     // MFMA scan: bf16 queries, maxima, tau, counters, candidate lists
     hrs_workspace ws_keys;     // result keys when the caller asks only for distances / rows

@@ -554,6 +554,269 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
 }
 
 
+
+// ---- the int8 main pass on v_mfma_i32_16x16x64_i8 ---------------------------------------------------------------
+// Same work, geometry and results as k_mfma_scan<KS, 64, 0, 2, true> (eight waves, 64 queries per wave, tiles of 64
+// rows through the same LDS image, barriers at every second tile boundary), on the 16 x 16 x 64 shape: per 32-row
+// group a wave issues 2 row halves x 4 query groups x KS/2 k-steps MFMAs of half the cycles each, and every corpus
+// fragment read from LDS feeds four of them.  The matrix pipe takes the same cycles either way, but under load the chip
+// holds a higher clock on this shape: an LDS-fed loop on random int8 operands ran 9 to 12 % faster with it
+// (tools/micro/mfma_micro.hip).  A lane of the 16 x 16 result holds four rows of ONE of sixteen queries, so a lane
+// carries the thresholds of four queries (one per query group) instead of two.
+// Query fragments: [Bpad / 16][KS / 2][4 depth quarters][16 queries][16 bytes] (k_convert_q_i8 writes them beside the
+// 32 x 32 form, which the sampled passes keep using).
+__device__ __forceinline__ size_t qfrag16_offset(int q, int c, int k64) {  // byte c of query q's padded int8 row
+    return ((size_t)(q >> 4) * k64 + (c >> 6)) * 1024 + ((c >> 4) & 3) * 256 + (q & 15) * 16 + (c & 15);
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __restrict__ qb16) {
+    constexpr int TR = 64, NW = 8, QG = 4, K64 = KS / 2;
+    constexpr int RB = KS * 32, TILE_BYTES = TR * RB, NBUF = 4, IPW = TR * KS / (32 * NW), NSUB = 2;
+    constexpr int STG = scan_stage(true), PPR = 2 * KS;
+    constexpr int SWB = (PPR % 16 == 0) ? 4 : 3;
+    constexpr int NB = 1 << (SWB - 2);   // per-lane fragment bases: k-steps NB apart differ by an immediate
+    constexpr int FSTEP = 16 << SWB;
+    constexpr int NF = 2 * K64;          // fragments per 32-row group: (k-step, row half)
+    static_assert(KS % 2 == 0 && KS <= 12 && PPR % 8 == 0, "depth up to 384 in steps of 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kg = lane >> 4;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int qg = loc % a.nqg;
+    const int nslices = HRS_NUM_CU / a.nqg;
+    const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
+    const int q0 = qg * (MF_QPB * 2) + wv * 64;
+
+    i32x4 qf[QG][K64];
+    float taum[QG];
+    float2 kq[QG];
+    auto load_queries = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int s = 0; s < K64; ++s) qf[g][s] = *(const i32x4*)(qb16 + ((size_t)((q0 >> 4) + g) * K64 + s) * 1024 + lane * 16);
+        float tau[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            tau[g] = raised_tau(a, q0 + g * 16 + j);
+            if (slice == 0 && kg == 0) a.tau_out[q0 + g * 16 + j] = tau[g];  // one writer per query
+            kq[g] = a.kq[q0 + g * 16 + j];
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int s = 0; s < K64; ++s) asm volatile("" : "+v"(qf[g][s]));
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            asm volatile("" : "+v"(tau[g]), "+v"(kq[g].x), "+v"(kq[g].y));
+            taum[g] = tau[g] - fabsf(tau[g]) * 4e-7f;  // (as in k_mfma_scan: lowered by more than the compare's roundings)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store above too: the loop's waits count requests
+    };
+
+    const int64_t t_begin = a.tiles * slice / nslices;
+    const int64_t t_end = a.tiles * (slice + 1) / nslices;
+    const int64_t count = t_end - t_begin;
+    auto tile_at = [&](int64_t n) -> int64_t { return t_begin + (n >= count ? count - 1 : n); };
+    int srcoff[IPW];
+#pragma unroll
+    for (int ii = 0; ii < IPW; ++ii) {
+        const int g = (wv * IPW + ii) * 64 + lane;
+        const int r = g / PPR, p = g % PPR;
+        srcoff[ii] = r * RB + ((p ^ (SWB == 4 ? (r & 15) : ((r >> 1) & 7))) << 4);
+    }
+    const uint32_t lds0 = lds_addr_of(smem);
+    auto issue = [&](int64_t n, int buf) {
+        const char* base = uniform_ptr(a.shadow + tile_at(n) * (int64_t)TILE_BYTES);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + wv * (IPW * 1024));
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
+    };
+    // read side: fragment (k-step s, row half rh) of a 32-row group: row 16 rh + j, 16-byte piece 4 s + kg of the row,
+    // stored at (4 s + kg) ^ w(row); w does not depend on the row half (w = row & 15, or (row >> 1) & 7)
+    int bc[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) bc[c] = (int)lds0 + j * RB + (((4 * c + kg) ^ (SWB == 4 ? j : ((j >> 1) & 7))) << 4);
+
+    constexpr int WCAP = STG / NW;
+    uint64_t* const wk = (uint64_t*)(smem + NBUF * TILE_BYTES) + wv * WCAP;
+    uint32_t* const wq = (uint32_t*)((uint64_t*)(smem + NBUF * TILE_BYTES) + STG) + wv * WCAP;
+    int wcnt = 0;
+    auto to_memory = [&](uint64_t key, int q) __attribute__((always_inline)) {
+        if (!a.mask || a.mask[(int64_t)(uint32_t)key - a.row_offset]) {
+            const int pos = atomicAdd(&a.cnt[q * MF_CNT_STRIDE], 1);
+            if (pos < HRS_CAND_CAP_BIG) a.cand[(size_t)q * HRS_CAND_CAP_BIG + pos] = key;
+        }
+    };
+    auto flush_wave = [&]() __attribute__((always_inline)) {
+        for (int e = lane; e < wcnt; e += 64) to_memory(wk[e], (int)wq[e]);
+        wcnt = 0;
+    };
+    auto record = [&](bool hit, uint64_t key, int q) __attribute__((always_inline)) {
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(hit);
+        if (bal == 0) return;
+        const int np = __builtin_popcountll(bal);
+        if (wcnt + np > WCAP) flush_wave();
+        const int slot = wcnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (hit) {
+            if (slot < WCAP) {
+                wk[slot] = key;
+                wq[slot] = (uint32_t)q;
+            } else {
+                to_memory(key, q);
+            }
+        }
+        wcnt = __builtin_amdgcn_readfirstlane(min(wcnt + np, WCAP));
+    };
+
+    if (count > 0) {
+        typedef const __attribute__((address_space(3))) char* lds_cptr;
+        typedef const __attribute__((address_space(3))) i32x4* lds_frag;
+        constexpr int PF = 4 < NF ? 4 : NF;
+        typedef float f32xg __attribute__((ext_vector_type(8)));
+        auto terms_request = [&](int64_t tile, f32xg& dst) __attribute__((always_inline)) {
+            const char* p = uniform_ptr(a.group + tile * NSUB);
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst) : "s"(p));
+        };
+        issue(0, 0);
+        load_queries();
+#pragma unroll
+        for (int g = 1; g < NBUF; ++g) issue(g, g);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int buf = 0;
+        if (q0 >= a.nq) {
+            for (int64_t n = 0; n + 1 < count; ++n) {
+                if (n & 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue(n + 3, (buf + 3) & 3);
+                    issue(n + 4, buf);
+                }
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+        } else {
+            lds_cptr tb[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)bc[c];
+            // fragment f = 2 s + rh of the 32-row group sb of the current tile
+            auto frag_ptr = [&](int f, int sb) __attribute__((always_inline)) {
+                const int s = f >> 1, rh = f & 1;
+                return (lds_frag)(tb[s & (NB - 1)] + (sb * 32 + rh * 16) * RB + (s / NB) * FSTEP);
+            };
+            i32x4 pre[PF];
+#pragma unroll
+            for (int f = 0; f < PF; ++f) pre[f] = *frag_ptr(f, 0);
+            for (int64_t n = 0; n < count; ++n) {
+                const int64_t tile = tile_at(n);
+                f32xg terms;
+                terms_request(tile, terms);
+                f32x4 scw[NSUB];
+#pragma unroll
+                for (int sb = 0; sb < NSUB; ++sb) {
+                    i32x4 acc[2][QG];
+#pragma unroll
+                    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) acc[rh][g] = (i32x4){0, 0, 0, 0};
+                    i32x4 av[NF];
+#pragma unroll
+                    for (int f = 0; f < PF; ++f) av[f] = pre[f];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        if (f + PF < NF) av[f + PF] = *frag_ptr(f + PF, sb);
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) acc[f & 1][g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[f], qf[g][f >> 1], acc[f & 1][g], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int f = 0; f < NF - PF; ++f) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, QG, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, QG * PF, 0);
+                    if (sb == 0) {
+                        __builtin_amdgcn_sched_barrier(0);  // (the wait stays behind the block's last MFMA)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(terms)::"memory");
+                        scw[0] = __builtin_shufflevector(terms, terms, 0, 1, 2, 3);
+                        scw[1] = __builtin_shufflevector(terms, terms, 4, 5, 6, 7);
+                    }
+                    // lane (j, kg) holds rows 16 rh + 4 kg + r (r = 0..3) of query q0 + 16 g + j, for g = 0..3
+                    auto epilogue = [&]() __attribute__((always_inline)) {
+                        const float gs = scw[sb].w;  // s_g itself (.x is its reciprocal)
+#ifdef HRS_SCAN_NOEPI  // timing only: a main pass that never looks at its accumulators (no results)
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) asm volatile("" ::"v"(acc[0][g]), "v"(acc[1][g]));
+                        return;
+#endif
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) {
+                            int m = max(max(acc[0][g][0], acc[0][g][1]), acc[0][g][2]);
+                            m = max(max(m, acc[0][g][3]), acc[1][g][0]);
+                            m = max(max(m, acc[1][g][1]), acc[1][g][2]);
+                            m = max(m, acc[1][g][3]);
+                            // s_g (acc + xb) > tau  <=>  acc > tau / s_g - xb, xb = |qi| E_g + |eq| (C_g + E_g): see k_mfma_scan
+                            float tf = fmaf(taum[g], scw[sb].x, -0.5f);
+                            tf = fmaf(-kq[g].x, scw[sb].y, tf);
+                            tf = fmaf(-kq[g].y, scw[sb].z, tf);
+                            int ti;
+                            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ti) : "v"(tf));
+                            if (__builtin_amdgcn_ballot_w64(m > ti) != 0) {  // wave-uniform: some lane holds such a row
+                                const float xb = fmaf(kq[g].x, scw[sb].y, kq[g].y * scw[sb].z);
+#pragma unroll
+                                for (int rh = 0; rh < 2; ++rh) {
+                                    const int m4 = max(max(acc[rh][g][0], acc[rh][g][1]), max(acc[rh][g][2], acc[rh][g][3]));
+                                    if (__builtin_amdgcn_ballot_w64(m4 > ti) == 0) continue;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const bool hit = acc[rh][g][r] > ti;
+                                        if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                                        const uint32_t row = (uint32_t)tile * TR + sb * 32 + rh * 16 + 4 * kg + r;
+                                        const float score = ((float)acc[rh][g][r] + xb) * gs;
+                                        record(hit && row < (uint32_t)a.N, ((uint64_t)(~f32_orderable(score)) << 32) | (uint32_t)(row + (uint32_t)a.row_offset), q0 + g * 16 + j);
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    // The two waves of a SIMD would otherwise leave every barrier in step: both in their MFMAs, then both
+                    // in the vector work on their results, with the matrix pipe idle.  Waves 0..3 look at the last group's
+                    // results in front of the barrier, waves 4..7 behind it, which sets the partners half a phase apart.
+                    auto next_tile = [&]() __attribute__((always_inline)) {
+                        if (n & 1) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            issue(n + 3, (buf + 3) & 3);
+                            issue(n + 4, buf);
+                        }
+                        buf = buf + 1 == NBUF ? 0 : buf + 1;
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
+#pragma unroll
+                        for (int f = 0; f < PF; ++f) pre[f] = *frag_ptr(f, 0);
+                    };
+                    const bool early = sb + 1 == NSUB && n + 1 < count && (n & 1) && wv < 4;
+                    if (sb + 1 < NSUB) {
+#pragma unroll
+                        for (int f = 0; f < PF; ++f) pre[f] = *frag_ptr(f, sb + 1);
+                    } else if (n + 1 < count && !early) {
+                        next_tile();
+                    }
+                    epilogue();
+                    if (early) next_tile();
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flush_wave();
+    } else {
+        load_queries();  // (for the threshold that the first slice publishes)
+    }
+}
+
 // ---- depth 1024 (bge-large class) ----------------------------------------------------------------
 // 32 queries x 1024 depth are 256 registers per lane: more than the arch-VGPR half of the register
 // file, so a workgroup is four waves (one per SIMD, 512 registers each) and most query fragments live
@@ -841,6 +1104,7 @@ __global__ __launch_bounds__(256) void k_build_shadow_i8(const float* __restrict
         // an all-zero group scores exactly 0: a huge reciprocal keeps it out for any positive threshold
         pre_terms[g] = make_float4(gs, eg, cg + eg, 0.f);
         main_terms[g] = make_float4(gs > 0.f ? 1.0f / gs : 1e30f, eg, cg + eg, gs);
+
     }
 }
 
@@ -1038,7 +1302,7 @@ __device__ __forceinline__ void zero_words(const ZeroList& z) {
 // fp64, the scale, and the two norms of the error bound: of the int8 values and of the residuals
 // (q / scale - int8, in real arithmetic), rounded up.  One wave per query.
 __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ Q, int B, int D, int Bpad, int Dpad,
-                                                      int8_t* __restrict__ qb, double* __restrict__ qn2,
+                                                      int8_t* __restrict__ qb, int8_t* __restrict__ qb16, double* __restrict__ qn2,
                                                       float* __restrict__ qscale, float2* __restrict__ kq, ZeroList z) {
     zero_words(z);
     const int lane = threadIdx.x & 63;
@@ -1054,6 +1318,7 @@ __global__ __launch_bounds__(256) void k_convert_q_i8(const float* __restrict__ 
         const float v = (q < B && c < D) ? Q[(size_t)q * D + c] : 0.f;
         const int qi = sq > 0.f ? (int)rintf(v / sq) : 0;
         qb[qfrag_offset(q, c >> 5, (c >> 4) & 1, Dpad >> 5) + (c & 15)] = (int8_t)qi;
+        if (qb16) qb16[qfrag16_offset(q, c, Dpad >> 6)] = (int8_t)qi;  // the main pass on the 16 x 16 x 64 shape reads this form
         const double res = sq > 0.f ? (double)v / (double)sq - qi : 0.0;
         i2 += (double)(qi * qi);
         e2 += res * res;
@@ -1488,6 +1753,20 @@ static int launch_scan_qt(const MfmaArgs& a, int mode, int device, hipStream_t s
     return HRS_OK;
 }
 
+template <int KS>
+static int launch_scan16(MfmaArgs a, const char* qb16, const hrs_corpus* c, int device, hipStream_t st) {
+    a.group = c->group_main;
+    const size_t lds = scan_lds_bytes(64 * KS * 32, true);
+    static hrs_per_device_once attr;
+    if (attr.need(device)) {
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan16<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.done(device);
+    }
+    hipLaunchKernelGGL((k_mfma_scan16<KS>), dim3(HRS_NUM_CU), dim3(512), lds, st, a, qb16);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
 // Two 32-query tiles per wave (each corpus fragment read from LDS feeds two MFMAs) where the query
 // fragments of 64 queries fit the wave's registers: the int8 shadow up to 12 k-steps (depth 384).
 template <int KS, bool I8>
@@ -1556,6 +1835,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
     const size_t o_ctrl = carve(256);
     const size_t o_qlist = carve((size_t)B * sizeof(int32_t));
     const size_t o_qb = carve((size_t)BC * Dpad * sizeof(__bf16));
+    const size_t o_qb16 = carve((size_t)BC * Dpad);
     const size_t o_qn = carve((size_t)BC * sizeof(double));
     const size_t o_max = carve((size_t)BC * HRS_MAX_STREAMS * sizeof(float));
     const size_t o_tau = carve((size_t)BC * sizeof(float));
@@ -1587,6 +1867,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         // 64 queries per wave for large batches on the shallow int8 kernels
         // on the shallow int8 kernels: 64 queries per wave; batches of up to 256 split the rows of a tile as well
         const int qt = (i8 && KS <= 12 && !ctx->scan_qt1) ? (bpad >= 512 ? 2 : 3) : 1;
+        // the main pass of the large int8 batches runs on the 16 x 16 x 64 MFMA shape (k_mfma_scan16)
+        const bool shape16 = i8 && qt == 2 && TR == 64 && KS % 2 == 0 && !ctx->scan_shape32;
         const int nqg = bpad / (wide ? 128 : MF_QPB * (qt == 2 ? 2 : 1));
         const int nslices = HRS_NUM_CU / nqg;
         // cleared by the convert kernel: this chunk's deferred-queue length; for the first chunk also the
@@ -1601,8 +1883,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         if (!do_scan) {
         } else if (i8)
             hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
-                               bpad, Dpad, (int8_t*)(ws + o_qb), (double*)(ws + o_qn), (float*)(ws + o_qs),
-                               (float2*)(ws + o_kq), z);
+                               bpad, Dpad, (int8_t*)(ws + o_qb), shape16 ? (int8_t*)(ws + o_qb16) : nullptr, (double*)(ws + o_qn),
+                               (float*)(ws + o_qs), (float2*)(ws + o_kq), z);
         else
             hipLaunchKernelGGL(k_convert_q, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
                                bpad, Dpad, (__bf16*)(ws + o_qb), (double*)(ws + o_qn), z);
@@ -1688,7 +1970,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         if ((rc = tau_steps(scan))) return rc;                                                       \
         HRS_SCAN_PROF_RESET                                                                          \
         hrs_prof_begin(ctx, st);                                                                     \
-        rc = scan(0);                                                                                \
+        if constexpr (I8_ && KS_ <= 12 && KS_ % 2 == 0 && TR_ == 64) {                               \
+            rc = shape16 ? launch_scan16<KS_>(a, (const char*)(ws + o_qb16), c, ctx->device, st) : scan(0); \
+        } else {                                                                                     \
+            rc = scan(0);                                                                            \
+        }                                                                                            \
         hrs_prof_end(ctx, st);                                                                       \
         if (rc) return rc;                                                                           \
     } break;

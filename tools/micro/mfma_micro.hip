@@ -137,6 +137,99 @@ __global__ __launch_bounds__(NW * 64) void kst(float* out, const char* src, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// The same stage with the 16x16 MFMA shapes at the same output tile per wave (32 rows x 64 queries): fragment s is
+// (k-step s >> 1, row half s & 1) and feeds four MFMAs, one per group of 16 queries (v_mfma_i32_16x16x64_i8 /
+// v_mfma_f32_16x16x32_bf16: half the cycles of the 32x32 forms, a quarter of the output).  Same LDS bytes, same
+// operand registers (48 query fragments), same matrix-pipe cycles per stage.
+typedef __attribute__((ext_vector_type(4))) float f32x4m;
+template <int S, int NW, bool I8 = false>
+__global__ __launch_bounds__(NW * 64) void kst16(float* out, const char* src, int stages) {
+    constexpr int KS = 24, PF = 4, STAGE = 24576, NBUF = 6, IPW = STAGE / (NW * 1024);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int j = threadIdx.x; j < NBUF * STAGE / 4; j += blockDim.x) ((float*)lds)[j] = 0.001f * (j & 255);
+    __syncthreads();
+    bf16x8 q[4][KS / 2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned hsh = (lane * 131 + j * 31 + s * 7919 + g * 104729) * 2654435761u;
+                q[g][s][j] = (__bf16)(((int)(hsh >> 16) - 32768) / 327680.0f);
+            }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s) asm volatile("" : "+a"(q[g][s]));
+    typedef const __attribute__((address_space(3))) bf16x8* lp;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const int i = lane & 15, kg = lane >> 4;
+    f32x4m c[2][4];
+    float acc = 0.f;
+    const char* base = src;
+    for (int g = 0; g < stages; ++g) {
+        const unsigned sb = lds0 + (g % NBUF) * STAGE + i * 768;
+        if (S >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+        if (S >= 1) __builtin_amdgcn_s_barrier();
+        if (S >= 2) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + ((g + NBUF - 1) % NBUF) * STAGE + wv * IPW * 1024);
+            const char* b2 = base + (size_t)((blockIdx.x * 64 + (g & 63)) % 4096) * STAGE;
+            const char* b3 = (const char*)(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((size_t)b2 >> 32)) << 32) | (size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)b2));
+#pragma unroll
+            for (int ii = 0; ii < IPW; ++ii) glds16(b3, (wv * IPW + ii) * 1024 + lane * 16, dst + ii * 1024);
+        }
+        // fragment s: rows 16 (s & 1) + i, 16-byte piece 4 (s >> 1) + kg of the row (48 pieces), XOR-permuted as the scan does
+        auto addr = [&](int s) { return sb + (s & 1) * 16 * 768 + ((((4 * (s >> 1) + kg) & 15) ^ (i & 15)) * 16) + ((4 * (s >> 1)) >> 4) * 256; };
+        bf16x8 av[KS];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) av[s] = *(lp)(size_t)addr(s);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + PF < KS) av[s + PF] = *(lp)(size_t)addr(s + PF);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (I8) {
+                    if (s < 2)
+                        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(c[s & 1][gq]) : "v"(av[s]), "a"(q[gq][s >> 1]));
+                    else
+                        asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c[s & 1][gq]) : "v"(av[s]), "a"(q[gq][s >> 1]));
+                } else {
+                    if (s < 2)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c[s & 1][gq]) : "v"(av[s]), "a"(q[gq][s >> 1]));
+                    else
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[s & 1][gq]) : "v"(av[s]), "a"(q[gq][s >> 1]));
+                }
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]));
+        float m = c[0][0][0];
+        for (int hh = 0; hh < 2; ++hh)
+            for (int gq = 0; gq < 4; ++gq)
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, c[hh][gq][r]);
+        acc = fmaxf(acc, m);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+template <int S, int NW, bool I8 = false>
+void runst16(const char* name, float* out, const char* src) {
+    const int stages = 5000, lds = 6 * 24576;
+    CHECK(hipFuncSetAttribute((const void*)kst16<S, NW, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((kst16<S, NW, I8>), dim3(256), dim3(NW * 64), lds, 0, out, src, 50);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((kst16<S, NW, I8>), dim3(256), dim3(NW * 64), lds, 0, out, src, stages);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double mfma = (double)stages * 96 * NW * 256;  // 24 fragments x 4 MFMAs, each a quarter of a 32x32 one's work
+    printf("%-46s waves=%d  %.3f ms  %.0f T(FL)OP/s\n", name, NW, ms, mfma * (I8 ? 32768 : 16384) / (ms * 1e-3) / 1e12);
+}
+
 template <int S, int NW, bool I8 = false>
 void runst(const char* name, float* out, const char* src) {
     const int stages = 5000, lds = 6 * 24576;
@@ -205,5 +298,18 @@ int main() {
     runst<2, 4>("staged + barrier + LDS-DMA", out, src);
     runst<0, 4, true>("i8 staged: ds_read -> 2 MFMA", out, src);
     runst<2, 4, true>("i8 staged + barrier + LDS-DMA", out, src);
+    runst<0, 8, true>("i8 staged: ds_read -> 2 MFMA", out, src);
+    runst<2, 8, true>("i8 staged + barrier + LDS-DMA", out, src);
+    // the 16x16 shapes at the same output tile per wave, alternating with the 32x32 ones on the same data
+    for (int rep = 0; rep < 2; ++rep) {
+        runst<2, 4, false>("bf16 32x32x16 staged + barrier + LDS-DMA", out, src);
+        runst16<2, 4, false>("bf16 16x16x32 staged + barrier + LDS-DMA", out, src);
+        runst<2, 4, true>("i8 32x32x32 staged + barrier + LDS-DMA", out, src);
+        runst16<2, 4, true>("i8 16x16x64 staged + barrier + LDS-DMA", out, src);
+        runst<2, 8, true>("i8 32x32x32 staged + barrier + LDS-DMA", out, src);
+        runst16<2, 8, true>("i8 16x16x64 staged + barrier + LDS-DMA", out, src);
+        runst<0, 4, true>("i8 32x32x32 staged: reads + MFMA only", out, src);
+        runst16<0, 4, true>("i8 16x16x64 staged: reads + MFMA only", out, src);
+    }
     return 0;
 }
