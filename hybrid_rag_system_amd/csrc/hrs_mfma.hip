@@ -420,10 +420,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         }
                     }
                 }
-                if (sb + 1 < WSUB) {
-#pragma unroll
-                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
-                } else if (n + 1 < count) {
+                auto next_tile = [&]() __attribute__((always_inline)) {
                     if (!PAIR) {
                         // tile boundary: tile n+1 has landed once the younger tiles alone are outstanding
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
@@ -443,6 +440,16 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                     for (int c = 0; c < NB; ++c) tb[c] = (lds_cptr)(size_t)(uint32_t)(bc[c] + buf * TILE_BYTES);
 #pragma unroll
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (s / NB) * FSTEP);
+                };
+                // Main pass: the two waves of a SIMD would leave every barrier in step -- both in their MFMAs, then both
+                // in the vector work on their results, the matrix pipe idle.  Waves 0..3 look at the last group's results
+                // in front of the barrier, waves 4..7 behind it, which sets the partners half a phase apart.
+                const bool early = MODE == 0 && !RS && sb + 1 == WSUB && n + 1 < count && (!PAIR || (n & 1)) && wv < 4;
+                if (sb + 1 < WSUB) {
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
+                } else if (n + 1 < count && !early) {
+                    next_tile();
                 }
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
@@ -520,6 +527,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         }
                     }
                 }
+                if (early) next_tile();
             }
         }
         }  // waves with queries
