@@ -377,6 +377,7 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     out[0] = h[0];
     out[1] = h[1];
     out[2] = h[2];
+    if (getenv("HRS_STATS_VERBOSE")) fprintf(stderr, "hrs_score_stats: fallbacks %lld, longest list %lld, overflows %lld, queries re-scored in more than one round %lld\n", (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3]);
 #ifdef HRS_SCAN_PROF
     {
         int64_t g[16];

@@ -1458,6 +1458,7 @@ struct SelectArgs {
     int32_t* nflag2;
     long long* stats;    // [0] fallbacks, [1] max candidates, [2] overflows
     int qbase;           // first query of this chunk
+    int first_rows;      // rows re-scored in the first round
 };
 
 // Two sizes of the same kernel.  The small one (lists up to HRS_CAND_CAP, re-scored prefix up to HRS_RESCORE_MAX
@@ -1551,8 +1552,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
     int done = 0;                       // candidates [0, done) are re-scored
     // first round: the rows that must be re-scored for a proof are those whose recorded bound reaches the k-th best
     // exact score -- for the int8 shadow several times k, rarely more than 8 k + 48
-    int first = (8 * a.k + 48 + 63) & ~63;
-    if (first > HRS_RESCORE) first = HRS_RESCORE;
+    int first = a.first_rows;
     int want = c < first ? c : first;
     bool accept = false, defer = false;
 #ifdef HRS_SEL_PROF
@@ -1707,7 +1707,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
         ok = accept;
         atomicMax((unsigned long long*)&a.stats[1], (unsigned long long)craw);
         if (overflow) atomicAdd((unsigned long long*)&a.stats[2], 1ull);
-        if (done > HRS_RESCORE) atomicAdd((unsigned long long*)&a.stats[3], 1ull);
+        if (done > a.first_rows) atomicAdd((unsigned long long*)&a.stats[3], 1ull);
         if (defer) {
             a.qlist2[atomicAdd(a.nflag2, 1)] = ql;
         } else if (!accept) {
@@ -1950,7 +1950,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
             hipLaunchKernelGGL(k_pick_tau, dim3(bpad), dim3(256), 0, st, a.maxima, M, j, (float*)(ws + o_tau), a.cnt,
                                (float*)(ws + o_lad), (int*)(ws + o_hist), bc, i8 ? (const float*)(ws + o_qs) : nullptr);
             // the ladder only has to be right within a factor of two: half the sample of the first pass
-            const int ss2 = (int64_t)2 * ss * 4 <= min_len ? 2 * ss : ss;
+            static const int ss2_env = getenv("HRS_SS2_MULT") ? atoi(getenv("HRS_SS2_MULT")) : 2;
+            const int ss2 = (int64_t)ss2_env * ss * 4 <= min_len ? ss2_env * ss : ss;
             a.ss = ss2;
             a.raise_ss = ss2;
             r = scan(2);
@@ -2058,6 +2059,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.nflag = nflag;
         s.stats = (long long*)ctx->stats_dev;
         s.qbase = qbase;
+        {
+            static const int first_env = getenv("HRS_SEL_FIRST") ? atoi(getenv("HRS_SEL_FIRST")) : 0;
+            int first = first_env > 0 ? first_env : ((8 * k + 48 + 63) & ~63);
+            s.first_rows = first > HRS_RESCORE ? HRS_RESCORE : first;
+        }
         // a proof needs about a quarter of the target re-scored (the rows whose bound reaches the k-th exact score); for
         // deep rows and a large k that is often more than the small variant's prefix, and what it has re-scored by
         // then (4 KB a row) is read again by the large one
