@@ -218,6 +218,12 @@ extern "C" int hrs_score_topk_levels(hrs_ctx* ctx, hrs_corpus* c, const float* Q
                 (long long)row_pitch);
     if (B == 0) return HRS_OK;
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    // all classes in one pass per four queries where the kernel's layout applies (HRS_LEVELS_BY_PASS: the older form)
+    static const bool by_pass = getenv("HRS_LEVELS_BY_PASS") != nullptr;
+    if (!by_pass) {
+        rc = hrs_launch_exact_levels(ctx, c, Q_dev, B, k, space, level_dev, row_pitch, levels, keys_dev, (hipStream_t)stream);
+        if (rc != HRS_ERR_UNSUPPORTED) return rc;
+    }
     // one masked pass per level: the rows whose byte equals the level, each query under its own mask
     for (int l = 0; l < levels; ++l) {
         rc = hrs_launch_exact(ctx, c, Q_dev, B, k, space, level_dev, nullptr, nullptr, keys_dev + (size_t)l * k, (hipStream_t)stream,

@@ -47,7 +47,13 @@ struct ExactArgs {
     uint64_t* partial;  // [nq][gridDim.x][k]
     int64_t tiles;
     const double* qd;   // SQ kernels: the queries as fp64, [nq][D] (written by k_queries_f64 before the scan)
+    // LV kernels: one list per (query, class).  Row r belongs to class level[q * level_pitch + r] of query q; this launch
+    // serves the classes lv0 .. lv0 + nlv - 1 of `levels`, and partial is [nq][levels][gridDim.x][k]
+    const uint8_t* level;
+    int64_t level_pitch;  // a multiple of 4, >= N
+    int lv0, nlv, levels;
 };
+#define ELV_MAX 64  // classes one launch of an LV kernel serves (nlv * k <= HRS_EXACT_CB - ER as well)
 
 // fp32 -> fp64 copy of the queries for the scan kernels that take them through the scalar cache
 __global__ void k_queries_f64(const float* __restrict__ Q, int64_t n, double* __restrict__ qd) {
@@ -62,8 +68,15 @@ __global__ void k_queries_f64(const float* __restrict__ Q, int64_t n, double* __
 // EXT: the forms only the extended entry points use (a resume key per query, a mask per query, a mask compared for
 // equality with a value).  They are compiled out of the plain scan: their conditional global loads at the end of a tile
 // make the compiler place a vmcnt(0) in front of the loop's counted wait, which drains the DMA ring at every segment.
-template <int SPACE, int BQ, bool SQ = false, bool EXT = false>
+// LV: the nearest k rows of EVERY class of every query in one pass over the corpus (the full-corpus hybrid mode: the
+// class of a row is the number of the query's keywords it holds).  A list in LDS holds the candidates of all classes as
+// (class : 8 | distance : 32 | row within this workgroup's slice : 24), so that one sort groups them by class; what a
+// class keeps is its first k, and each (query, class) has its own threshold (the distance half of a key: rows that tie
+// with it are admitted and the sort settles them).  The class bytes of a tile come in by LDS-DMA with the tile's
+// first segment -- 256 bytes per query, one 4-byte piece per lane -- so the loop still holds no load of the compiler's.
+template <int SPACE, int BQ, bool SQ = false, bool EXT = false, bool LV = false>
 __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
+    static_assert(!(EXT && LV), "a scan by classes takes no resume key and no other mask");
     typedef const __attribute__((address_space(4))) double* qd_ptr;
     constexpr int NQT = BQ > ESLOTS ? BQ / ESLOTS : 1;  // queries per thread
     constexpr int NSL = BQ < ESLOTS ? BQ : ESLOTS;      // query slots in use
@@ -78,6 +91,10 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
     uint64_t* aft = (uint64_t*)(qnorm + BQ);
     int* cnt = (int*)(aft + BQ);
     int* qidx = cnt + BQ;
+    // LV: [ENBUF][BQ][ER] class bytes of a tile (requested with the tile's first segment, up to ENBUF - 1 tiles ahead)
+    uint8_t* lvb = (uint8_t*)(qidx + BQ);
+    uint32_t* tau32 = (uint32_t*)(lvb + ENBUF * BQ * ER);  // LV: [BQ][ELV_MAX]
+    int* lstart = (int*)(tau32 + BQ * ELV_MAX);        // LV: [ELV_MAX] where a class begins in the sorted list
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,6 +123,8 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             tau[tid] = HRS_PAD_KEY;
             if (EXT) aft[tid] = a.after ? a.after[qidx[tid]] : 0ull;
         }
+        if (LV)
+            for (int e = tid; e < BQ * ELV_MAX; e += 256) tau32[e] = 0xFFFFFFFFu;
         __syncthreads();
         for (int e = tid; e < BQ * D; e += 256) qf32[e] = a.Q[(size_t)qidx[e / D] * D + e % D];
         __syncthreads();
@@ -144,6 +163,14 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)(step % ENBUF) * ESEG_BYTES + wv * (EIPW * 1024));
             const char* base = uniform_ptr(a.C + tile * ER * (int64_t)D + ch * EDC);
             const int64_t rows_left = a.N - tile * ER;
+            if (LV && ch == 0 && wv < BQ) {
+                // this wave's query: the class bytes of the tile's rows (requested ahead of the segment, so they have
+                // landed when it has; lanes past the end of the byte row repeat its last piece)
+                const int64_t left = a.level_pitch - tile * ER;
+                const int voff = (int)min((int64_t)lane * 4, left - 4);
+                const char* lb = uniform_ptr(a.level + (int64_t)__builtin_amdgcn_readfirstlane(qidx[wv]) * a.level_pitch + tile * ER);
+                glds4_asm(lb, voff, __builtin_amdgcn_readfirstlane(lds_addr_of(lvb) + (uint32_t)(((tile % ENBUF) * BQ + wv) * ER)));
+            }
             if (wpieces == EDC / 4 && rows_left >= ER) {
 #pragma unroll
                 for (int i = 0; i < EIPW; ++i) glds16_asm(base, fastoff[i], dst + i * 1024);
@@ -288,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                 bool live = row < a.N && qslot < NSL;
                 if (EXT) {
                     if (live && a.mask && a.mask_qstride == 0) live = a.mask_eq < 0 ? a.mask[row] != 0 : a.mask[row] == a.mask_eq;
-                } else {
+                } else if (!LV) {
                     if (live && a.mask) live = a.mask[row] != 0;
                 }
                 if (live) {
@@ -296,6 +323,11 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
 #pragma unroll
                     for (int b = 0; b < NQT; ++b) {
                         const int qb_i = qslot + NSL * b;
+                        int lv = 0;
+                        if (LV) {
+                            lv = (int)lvb[((tile % ENBUF) * BQ + qb_i) * ER + row_t] - a.lv0;
+                            if ((unsigned)lv >= (unsigned)a.nlv) continue;  // a class this launch does not serve
+                        }
                         if (EXT && a.mask_qstride) {  // a mask per query (rows grouped by their keyword match count)
                             const uint8_t mv = a.mask[(int64_t)qidx[qb_i] * a.mask_qstride + row];
                             if (a.mask_eq < 0 ? mv == 0 : mv != a.mask_eq) continue;
@@ -309,6 +341,14 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                             const double nqv = qnorm[qb_i];
                             d = (nqv == 0.0 || ncacc == 0.0) ? 1.0 : 1.0 - acc[b] / (sqrt(nqv) * sqrt(ncacc));
                         }
+                        if (LV) {
+                            const uint32_t d32 = f32_orderable((float)d);
+                            if (d32 <= tau32[qb_i * ELV_MAX + lv]) {
+                                const int pos = atomicAdd(&cnt[qb_i], 1);
+                                cand[qb_i * HRS_EXACT_CB + pos] = ((uint64_t)lv << 56) | ((uint64_t)d32 << 24) | (uint32_t)(row - tile_begin * ER);
+                            }
+                            continue;
+                        }
                         const uint64_t key = pack_key((float)d, grow);
                         if (key < tau[qb_i] && (!EXT || !a.after || key > aft[qb_i])) {
                             const int pos = atomicAdd(&cnt[qb_i], 1);
@@ -316,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                         }
                     }
                 }
-                if (a.mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!LV && a.mask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 // compact any list that could overflow during the next tile
                 for (int b = 0; b < BQ; ++b) {
@@ -325,6 +365,35 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
                         uint64_t* cb = cand + b * HRS_EXACT_CB;
                         for (int i = c + tid; i < HRS_EXACT_CB; i += 256) cb[i] = HRS_PAD_KEY;
                         bitonic_sort_u64(cb, HRS_EXACT_CB, tid, 256);
+                        if (LV) {
+                            // sorted by (class, distance, row): every class keeps its first k, the k-th sets its
+                            // threshold, the rest become padding and a second sort moves them behind what is kept
+                            for (int i = tid; i < c; i += 256) {
+                                const int l = (int)(cb[i] >> 56);
+                                if (i == 0 || (int)(cb[i - 1] >> 56) != l) lstart[l] = i;
+                            }
+                            if (tid == 0) cnt[b] = 0;
+                            __syncthreads();
+                            uint64_t nk[HRS_EXACT_CB / 256];
+#pragma unroll
+                            for (int u = 0; u < HRS_EXACT_CB / 256; ++u) {
+                                const int i = tid + u * 256;
+                                const uint64_t key = cb[i];
+                                bool keep = false;
+                                if (i < c) {
+                                    const int l = (int)(key >> 56), r = i - lstart[l];
+                                    keep = r < a.k;
+                                    if (r == a.k - 1) tau32[b * ELV_MAX + l] = (uint32_t)(key >> 24);
+                                }
+                                nk[u] = keep ? key : HRS_PAD_KEY;
+                                const int kept = __builtin_popcountll(__builtin_amdgcn_ballot_w64(keep));
+                                if (lane == 0 && kept) atomicAdd(&cnt[b], kept);
+                            }
+#pragma unroll
+                            for (int u = 0; u < HRS_EXACT_CB / 256; ++u) cb[tid + u * 256] = nk[u];
+                            bitonic_sort_u64(cb, HRS_EXACT_CB, tid, 256);
+                            continue;
+                        }
                         if (tid == 0) {
                             cnt[b] = min(c, a.k);
                             tau[b] = c >= a.k ? cb[a.k - 1] : HRS_PAD_KEY;
@@ -344,6 +413,27 @@ __global__ __launch_bounds__(256, 1) void k_exact_scan(ExactArgs a) {
             uint64_t* cb = cand + b * HRS_EXACT_CB;
             for (int i = c + tid; i < HRS_EXACT_CB; i += 256) cb[i] = HRS_PAD_KEY;
             bitonic_sort_u64(cb, HRS_EXACT_CB, tid, 256);
+            if (LV) {
+                for (int l = tid; l < a.nlv; l += 256) lstart[l] = -1;
+                __syncthreads();
+                for (int i = tid; i < c; i += 256) {
+                    const int l = (int)(cb[i] >> 56);
+                    if (i == 0 || (int)(cb[i - 1] >> 56) != l) lstart[l] = i;
+                }
+                __syncthreads();
+                // slot (class, rank) is written by one thread: the class's rank-th entry, or padding
+                for (int t = tid; t < a.nlv * a.k; t += 256) {
+                    const int l = t / a.k, r = t % a.k, at = lstart[l] + r;
+                    uint64_t key = HRS_PAD_KEY;
+                    if (lstart[l] >= 0 && at < c && (int)(cb[at] >> 56) == l) {
+                        const uint64_t e = cb[at];
+                        key = (((e >> 24) & 0xFFFFFFFFull) << 32) | (uint32_t)(tile_begin * ER + (int64_t)(e & 0xFFFFFFull) + a.row_offset);
+                    }
+                    a.partial[(((size_t)j * a.levels + a.lv0 + l) * gridDim.x + blockIdx.x) * a.k + r] = key;
+                }
+                __syncthreads();
+                continue;
+            }
             uint64_t* out = a.partial + ((size_t)j * gridDim.x + blockIdx.x) * a.k;
             for (int i = tid; i < a.k; i += 256) out[i] = cb[i];
             __syncthreads();
@@ -427,19 +517,27 @@ __global__ __launch_bounds__(256) void k_merge_lists_serial(MergeArgs a) {
     }
 }
 
-template <int SPACE, int BQ, bool SQ = false, bool EXT = false>
+template <int SPACE, int BQ, bool SQ = false, bool EXT = false, bool LV = false>
 static int launch_exact_t(const ExactArgs& a, int grid, int device, hipStream_t st) {
     size_t lds = ENBUF * ESEG_BYTES + EQ_FLOATS * sizeof(float) + 2 * BQ * EDC * sizeof(double) +
                  BQ * HRS_EXACT_CB * sizeof(uint64_t) + BQ * (2 * sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int)) + 64;
+    if (LV) lds += ENBUF * BQ * ER + BQ * ELV_MAX * sizeof(uint32_t) + ELV_MAX * sizeof(int);
     static hrs_per_device_once attr;  // the attribute belongs to the function on ONE device
     if (attr.need(device)) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ, SQ, EXT>,
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_exact_scan<SPACE, BQ, SQ, EXT, LV>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.done(device);
     }
-    hipLaunchKernelGGL((k_exact_scan<SPACE, BQ, SQ, EXT>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_exact_scan<SPACE, BQ, SQ, EXT, LV>), dim3(grid), dim3(256), lds, st, a);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
+}
+template <int SPACE>
+static int launch_exact_lv(const ExactArgs& a, int grid, int bq, int device, hipStream_t st) {
+    if (bq >= 4 && a.qd) return launch_exact_t<SPACE, 4, true, false, true>(a, grid, device, st);
+    if (bq >= 4) return launch_exact_t<SPACE, 4, false, false, true>(a, grid, device, st);
+    if (bq >= 2) return launch_exact_t<SPACE, 2, false, false, true>(a, grid, device, st);
+    return launch_exact_t<SPACE, 1, false, false, true>(a, grid, device, st);
 }
 
 template <int SPACE, bool EXT>
@@ -485,6 +583,9 @@ static int exact_run(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     a.after = after;
     a.partial = p0;
     a.tiles = tiles;
+    a.level = nullptr;
+    a.level_pitch = 0;
+    a.lv0 = a.nlv = a.levels = 0;
     int bq = nq_dev ? 4 : B;
     if (bq * c->D > EQ_FLOATS) bq = EQ_FLOATS / c->D;  // the pass's queries are staged in LDS as fp32
     // passes of four queries take the queries' values through the scalar cache, from an fp64 copy (qd: room for B x D
@@ -568,6 +669,92 @@ int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, 
     uint64_t* p0 = (uint64_t*)ctx->ws_partial.ptr;
     return exact_run(ctx, c, Q, B, k, space, mask, qlist, nq_dev, keys_out, p0, grid, !nq_dev, st, after, mask_qstride, mask_eq,
                      out_stride, un, qd_words ? (double*)(p0 + words) : nullptr);
+}
+
+// The nearest k rows of every class 0 .. levels-1 of every query (level[q * pitch + row] = the class of a row for query
+// q) -> keys_out [B][levels][k].  One pass over the corpus per four queries and per group of classes whose lists fit the
+// kernel's buffer (256 / k classes, at most ELV_MAX), then the merges of the plain scan with (query, class) in the
+// place of the query.  Returns HRS_ERR_UNSUPPORTED (nothing launched) where the kernel's layout does not apply.
+int hrs_launch_exact_levels(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* level,
+                            int64_t pitch, int levels, uint64_t* keys_out, hipStream_t st) {
+    const int grid = exact_grid(ctx, c);
+    const int64_t tiles = (c->N + ER - 1) / ER;
+    const int64_t slice_rows = ((tiles + grid - 1) / grid + 1) * ER;
+    if (pitch % 4 != 0 || k > HRS_EXACT_CB - ER || slice_rows > (1 << 24) || c->N <= 0 || ((uintptr_t)level & 3)) return HRS_ERR_UNSUPPORTED;
+    int per = (HRS_EXACT_CB - ER) / k;
+    if (per > ELV_MAX) per = ELV_MAX;
+    const int BL = B * levels;
+    const int g1 = (grid + 15) / 16;
+    const size_t words = exact_scratch_words(BL, grid, k), qd_words = (size_t)B * c->D;
+    int rc = hrs_ws_reserve(ctx, &ctx->ws_partial, (words + qd_words) * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t* p0 = (uint64_t*)ctx->ws_partial.ptr;
+    uint64_t* p1 = p0 + (size_t)BL * grid * k;
+    ExactArgs a;
+    a.C = c->C;
+    a.N = c->N;
+    a.D = c->D;
+    a.row_offset = c->row_offset;
+    a.Q = Q;
+    a.qlist = nullptr;
+    a.nq_dev = nullptr;
+    a.nq = B;
+    a.k = k;
+    a.mask = nullptr;
+    a.mask_qstride = 0;
+    a.mask_eq = -1;
+    a.after = nullptr;
+    a.partial = p0;
+    a.tiles = tiles;
+    a.level = level;
+    a.level_pitch = pitch;
+    a.levels = levels;
+    int bq = B;
+    if (bq * c->D > EQ_FLOATS) bq = EQ_FLOATS / c->D;
+    if (bq < 1) return HRS_ERR_UNSUPPORTED;
+    a.qd = nullptr;
+    if (bq >= 4) {
+        const int64_t n = (int64_t)B * c->D;
+        double* qd = (double*)(p0 + words);
+        hipLaunchKernelGGL(k_queries_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Q, n, qd);
+        a.qd = qd;
+    }
+    hrs_prof_begin(ctx, st);
+    for (int lv0 = 0; lv0 < levels; lv0 += per) {
+        a.lv0 = lv0;
+        a.nlv = levels - lv0 < per ? levels - lv0 : per;
+        if (space == HRS_SPACE_L2)
+            rc = launch_exact_lv<HRS_SPACE_L2>(a, grid, bq, ctx->device, st);
+        else if (space == HRS_SPACE_COSINE)
+            rc = launch_exact_lv<HRS_SPACE_COSINE>(a, grid, bq, ctx->device, st);
+        else
+            rc = launch_exact_lv<HRS_SPACE_IP>(a, grid, bq, ctx->device, st);
+        if (rc) return rc;
+    }
+    hrs_prof_end(ctx, st);
+    MergeArgs m;
+    m.nq_dev = nullptr;
+    m.nq = BL;
+    m.k = k;
+    m.per = 16;
+    m.qlist = nullptr;
+    m.out_stride = k;
+    m.dist_out = nullptr;
+    m.rows_out = nullptr;
+    m.in = p0;
+    m.nlists = grid;
+    if (g1 > 1) {
+        m.out = p1;
+        m.final_level = 0;
+        hipLaunchKernelGGL(k_merge_lists, dim3(BL * g1), dim3(256), 0, st, m);
+        m.in = p1;
+        m.nlists = g1;
+    }
+    m.out = keys_out;
+    m.final_level = 1;
+    hipLaunchKernelGGL(k_merge_lists, dim3(BL), dim3(256), 0, st, m);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------------

@@ -118,6 +118,77 @@ extern "C" int hrs_fuse_sort(hrs_ctx* ctx, const float* dist_dev, const int32_t*
     return HRS_OK;
 }
 
+// Full-corpus hybrid mode, second half.  One block per query, one thread per candidate: the nearest k rows of every
+// class (class index = keyword match count) are put nearest first (keys are unique: distance, then row), scored as
+// k_fuse_sort scores them -- the same separately rounded fp64 operations -- and ranked by (fused score descending,
+// position in the nearest-first list ascending), which is a stable descending sort of that list.
+__global__ __launch_bounds__(256) void k_classes_finish(const uint64_t* __restrict__ keys, const int32_t* __restrict__ q_term_offs,
+                                                        int levels, int k, double boost, int n, int64_t* __restrict__ rows,
+                                                        float* __restrict__ dist, int32_t* __restrict__ counts,
+                                                        double* __restrict__ combined) {
+    __shared__ uint64_t sk[256];
+    __shared__ double comb[256];
+    __shared__ int nvalid;
+    const int b = blockIdx.x, j = threadIdx.x, c = levels * k;
+    if (j == 0) nvalid = 0;
+    const uint64_t key = j < c ? keys[(size_t)b * c + j] : HRS_PAD_KEY;
+    const bool ok = key != HRS_PAD_KEY;
+    double mine = 0.0;
+    if (ok) {
+        const double d = (double)orderable_f32((uint32_t)(key >> 32));
+        double sem = __dsub_rn(1.0, d);
+        if (!(sem > 0.0)) sem = 0.0;
+        const int m = q_term_offs[b + 1] - q_term_offs[b];
+        const double kw = m > 0 ? __ddiv_rn((double)(j / k), (double)m) : 0.0;
+        const double w = __dsub_rn(1.0, boost);
+        mine = __dadd_rn(__dmul_rn(sem, w), __dmul_rn(kw, boost));
+    }
+    sk[j] = key;
+    comb[j] = mine;
+    __syncthreads();
+    if (ok) {
+        int rank = 0;
+        for (int i = 0; i < c; ++i) {
+            const uint64_t o = sk[i];
+            if (o == HRS_PAD_KEY) continue;
+            const double oc = comb[i];
+            rank += (oc > mine) || (oc == mine && o < key);
+        }
+        if (rank < n) {
+            const size_t at = (size_t)b * n + rank;
+            rows[at] = (int64_t)(key & 0xFFFFFFFFull);
+            dist[at] = orderable_f32((uint32_t)(key >> 32));
+            counts[at] = j / k;
+            combined[at] = mine;
+        }
+        atomicAdd(&nvalid, 1);
+    }
+    __syncthreads();
+    for (int i = nvalid + j; i < n; i += 256) {
+        const size_t at = (size_t)b * n + i;
+        rows[at] = -1;
+        dist[at] = __builtin_inff();
+        counts[at] = 0;
+        combined[at] = -1.0;
+    }
+}
+
+extern "C" int hrs_classes_finish(hrs_ctx* ctx, const uint64_t* keys_dev, const int32_t* q_term_offs_dev, int B, int levels,
+                                  int k, double boost, int n, int64_t* rows_dev, float* dist_dev, int32_t* counts_dev,
+                                  double* combined_dev, void* stream) {
+    HRS_REQUIRE(ctx && keys_dev && q_term_offs_dev && rows_dev && dist_dev && counts_dev && combined_dev,
+                "hrs_classes_finish: null argument");
+    HRS_REQUIRE(levels >= 1 && k >= 1 && (int64_t)levels * k <= 256, "hrs_classes_finish: levels * k = %lld outside [1, 256]",
+                (long long)levels * k);
+    HRS_REQUIRE(n >= 1, "hrs_classes_finish: n=%d < 1", n);
+    if (B <= 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_classes_finish, dim3(B), dim3(256), 0, (hipStream_t)stream, keys_dev, q_term_offs_dev, levels, k,
+                       boost, n, rows_dev, dist_dev, counts_dev, combined_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
 // Cross-shard merge: keys are globally unique (the row is part of the key), so the payload of each
 // output key is found again by position after sorting (key, source slot) pairs.
 __global__ __launch_bounds__(256) void k_merge_topk(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,

@@ -317,6 +317,8 @@ struct hrs_unpacked {
     float* dist = nullptr;
     int64_t* rows = nullptr;
 };
+int hrs_launch_exact_levels(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* level,
+                            int64_t pitch, int levels, uint64_t* keys_out, hipStream_t st);
 int hrs_launch_exact(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, int space, const uint8_t* mask,
                      const int32_t* qlist, const int32_t* nq_dev, uint64_t* keys_out, hipStream_t st,
                      const uint64_t* after = nullptr, int64_t mask_qstride = 0, int mask_eq = -1, int64_t out_stride = 0,

@@ -1,8 +1,9 @@
 """Host-side handles over the C ABI: one Engine per GPU, torch tensors as device memory.
 
 torch is plumbing here (allocation, streams, torch.distributed); every computation on the retrieval
-path is a HIP kernel of libhrs.so.  Nothing in this module computes on the CPU and nothing falls
-back to torch ops: a missing library or GPU raises.
+path is a HIP kernel of libhrs.so.  Nothing in this module computes on the CPU and no query falls
+back to torch ops: a missing library or GPU raises.  (The one torch computation here is an index
+build, InvertedPostings.from_forward, which sorts (term, row) pairs once per collection.)
 """
 import ctypes as C
 
@@ -340,14 +341,14 @@ class Engine:
         """Second half: keys [B, levels, n] (of one shard, or merged per class over all shards) -> the n best rows under
         the fused score.  The class index IS the keyword match count."""
         B, levels, k = keys.shape
-        lv = torch.arange(levels, dtype=torch.int32, device=self.device).view(1, levels, 1).expand(B, levels, k).contiguous()
-        skeys, scnt = self.merge_topk(keys.reshape(1, B, levels * k), lv.view(1, B, levels * k))  # all candidates, nearest first
-        dist, rows = self.unpack_keys(skeys)
-        combined, perm = self.fuse_sort(dist, scnt, q_term_offs, n, boost)
-        idx = perm.clamp(min=0).to(torch.int64)
-        miss = perm < 0
-        return {"rows": torch.gather(rows, 1, idx).masked_fill(miss, -1), "dist": torch.gather(dist, 1, idx).masked_fill(miss, float("inf")),
-                "counts": torch.gather(scnt, 1, idx).masked_fill(miss, 0), "combined": combined}
+        out = {"rows": torch.empty((B, n), dtype=torch.int64, device=self.device), "dist": torch.empty((B, n), dtype=torch.float32, device=self.device),
+               "counts": torch.empty((B, n), dtype=torch.int32, device=self.device), "combined": torch.empty((B, n), dtype=torch.float64, device=self.device)}
+        N.check(
+            N.lib().hrs_classes_finish(self._ctx, _ptr(keys), _ptr(q_term_offs), B, levels, k, float(boost), n, _ptr(out["rows"]), _ptr(out["dist"]),
+                                       _ptr(out["counts"]), _ptr(out["combined"]), _stream()),
+            "hrs_classes_finish",
+        )
+        return out
 
     def merge_classes(self, gathered):
         """gathered int64 [G, B, levels, n]: every shard's nearest n of every class -> [B, levels, n] over all shards."""

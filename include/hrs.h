@@ -253,9 +253,19 @@ int hrs_postings_release_inverted(hrs_ctx* ctx, hrs_inverted* p);
 int hrs_match_counts(hrs_ctx* ctx, hrs_inverted* p, const int32_t* q_terms_dev, const int32_t* q_term_offs_dev, int B,
                      int64_t row_pitch, uint8_t* counts_dev, void* stream);
 /* keys_dev uint64 [B, levels, k]: for every query and every l < levels the exact top-k (as hrs_score_topk, exact
- * streaming scan) among the rows with level_dev[b * row_pitch + r] == l. */
+ * streaming scan) among the rows with level_dev[b * row_pitch + r] == l.  One pass over the corpus per four queries
+ * serves 256 / k classes at once (row_pitch a multiple of 4, level_dev 4-byte aligned; otherwise one pass per class). */
 int hrs_score_topk_levels(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, int B, int k, int space,
                           const uint8_t* level_dev, int64_t row_pitch, int levels, uint64_t* keys_dev, void* stream);
+
+/* Second half of the full-corpus mode: keys_dev uint64 [B, levels, k] (of one shard, or merged per class over all
+ * shards; the class index is the keyword match count) -> the n best rows under the fused score of
+ * scripts/chromadb_helper.py:302-325 (arithmetic and order as hrs_fuse_sort; ties by distance, then row):
+ * rows_dev int64 [B, n] (-1 when missing), dist_dev fp32 [B, n] (+inf), counts_dev int32 [B, n] (0), combined_dev fp64
+ * [B, n] (-1).  levels * k <= 256. */
+int hrs_classes_finish(hrs_ctx* ctx, const uint64_t* keys_dev, const int32_t* q_term_offs_dev, int B, int levels, int k,
+                       double boost, int n, int64_t* rows_dev, float* dist_dev, int32_t* counts_dev, double* combined_dev,
+                       void* stream);
 
 /* ---- cross-shard merge (no counterpart in the single-process reference) -------------------- */
 /* keys_dev uint64 [G, B, k]: per-shard results gathered from G ranks (all-gather over RCCL is done

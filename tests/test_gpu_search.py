@@ -784,3 +784,35 @@ def test_full_corpus_hybrid_equals_brute_force(eng, space):
     inv.close()
     post.close()
     corpus.close()
+
+
+@pytest.mark.parametrize("space,n,d,b,k,levels", [("l2", 300_037, 32, 6, 10, 9), ("cosine", 150_001, 100, 5, 100, 7), ("ip", 70_000, 384, 3, 128, 3), ("l2", 1000, 64, 1, 5, 200)])
+def test_topk_by_classes_in_one_pass(eng, space, n, d, b, k, levels):
+    """hrs_score_topk_levels: the nearest k rows of every class of every query, all classes of four queries in one
+    pass over the corpus (groups of 256 / k classes per pass where they do not all fit: k = 100 and 128 here; several
+    tiles per workgroup so that lists are compacted on the way; a class byte beyond `levels` belongs to no class),
+    against one masked oracle search per (query, class)."""
+    rng = np.random.default_rng(n + k)
+    C = _unit(rng, n, d)
+    if space != "l2":
+        C *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    C[n // 3 : n // 3 + 40] = C[5]  # ties within and across classes
+    Q = _unit(rng, b, d)
+    Q[0] = C[5]
+    pitch = (n + 3) // 4 * 4
+    cls = np.zeros((b, pitch), np.uint8)
+    # skewed classes: most rows in class 0, the highest classes nearly or entirely empty
+    cls[:, :n] = np.minimum(rng.geometric(0.5, (b, n)) - 1, levels + 1).astype(np.uint8)
+    if levels > 2:
+        cls[0, :n][cls[0, :n] == levels - 1] = 0  # an empty class
+    off = 5000
+    corpus = eng.corpus(torch.from_numpy(C).cuda(), row_offset=off)
+    keys = eng.score_topk_levels(corpus, torch.from_numpy(Q).cuda(), k, levels, torch.from_numpy(cls).cuda(), space=space)
+    torch.cuda.synchronize()
+    got = _keys(keys)
+    assert got.shape == (b, levels, k)
+    for q in range(b):
+        for l in range(levels):
+            want = so.topk_keys(Q[q : q + 1], C, k, space, row_offset=off, mask=(cls[q, :n] == l).astype(np.uint8))
+            assert np.array_equal(got[q, l], want[0]), (q, l)
+    corpus.close()
