@@ -50,6 +50,8 @@ EXPORTS = [
     "hrs_score_topk_levels",
     "hrs_classes_finish",
     "hrs_fuse_sort",
+    "hrs_bm25_scores",
+    "hrs_fuse_sort_scores",
     "hrs_merge_topk",
     "hrs_unpack_keys",
     "hrs_synth_rows",
@@ -114,6 +116,8 @@ def lib():
             "hrs_classes_finish": ([vp, vp, vp, i32, i32, i32, dbl, i32, vp, vp, vp, vp, vp], i32),
             "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),
             "hrs_fuse_sort": ([vp, vp, vp, vp, i32, i32, dbl, i32, vp, vp, vp], i32),
+            "hrs_bm25_scores": ([vp, vp, vp, i64, dbl, dbl, dbl, vp, vp, vp, i32, i32, vp, vp], i32),
+            "hrs_fuse_sort_scores": ([vp, vp, vp, i32, i32, dbl, i32, vp, vp, vp], i32),
             "hrs_merge_topk": ([vp, vp, vp, i32, i32, i32, vp, vp, vp], i32),
             "hrs_unpack_keys": ([vp, vp, i64, vp, vp, vp], i32),
             "hrs_synth_rows": ([vp, u64, i64, i64, i32, i32, vp, vp], i32),

@@ -388,6 +388,8 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     {
         int64_t g[16];
         HRS_CHECK_HIP(hipMemcpy(g, ctx->stats_dev, sizeof(g), hipMemcpyDeviceToHost));
+        if (g[5] > 0 && g[6] == 0)  // the 16 x 16 x 64 main pass stamps cycles and 100 MHz ticks around its loop
+            fprintf(stderr, "main pass (16x16x64): clock in the loop %.3f GHz, loop %.1f us per workgroup\n", (double)g[4] / (double)g[5] * 0.1, g[5] / 256.0 / 100.0);
         fprintf(stderr, "scan per WG (us): prologue %.2f first-tile %.2f loop %.2f flush %.2f | start skew %.2f, first loop end after %.2f, last end after %.2f\n",
                 g[4] / 25600.0, g[5] / 25600.0, g[6] / 25600.0, g[7] / 25600.0, (g[9] - g[8]) / 100.0, (g[10] - g[8]) / 100.0, (g[11] - g[8]) / 100.0);
     }

@@ -54,11 +54,76 @@ extern "C" int hrs_keyword_counts(hrs_ctx* ctx, hrs_postings* p, const int32_t* 
     return HRS_OK;
 }
 
+// BM25 keyword score of every (query, candidate) pair, normalised to [0, 1): one wave per pair.  Lane j keeps the
+// occurrence count of query term j in the row (an integer: ballots over the row's term list, 64 entries at a time);
+// lane 0 then adds the terms' contributions in query order, every operation a separately rounded fp64 one:
+//   score = sum_j idf[t_j] * tf_j * (k1 + 1) / (tf_j + k1 * (1 - b + b * len / avg_len)),  kw = score / sum_j idf[t_j] * (k1 + 1)
+// (the denominator is the score of a row that holds every term infinitely often).  Terms outside [0, V) weigh nothing.
+__global__ __launch_bounds__(256) void k_bm25_scores(const int64_t* __restrict__ doc_offs, const int32_t* __restrict__ term_ids,
+                                                     int64_t N, int64_t row_offset, const double* __restrict__ idf, int64_t V,
+                                                     double avg_len, double k1, double bb, const int32_t* __restrict__ q_terms,
+                                                     const int32_t* __restrict__ q_term_offs, const int64_t* __restrict__ cand_rows,
+                                                     int B, int c, double* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)B * c) return;
+    const int b = (int)(pair / c);
+    const int64_t row = cand_rows[pair] - row_offset;
+    double score = 0.0, best = 0.0;
+    if (cand_rows[pair] >= 0 && row >= 0 && row < N) {
+        const int64_t p0 = doc_offs[row], p1 = doc_offs[row + 1];
+        const int t0 = q_term_offs[b], t1 = q_term_offs[b + 1];
+        const double norm = __dmul_rn(k1, __dadd_rn(__dsub_rn(1.0, bb), __dmul_rn(bb, __ddiv_rn((double)(p1 - p0), avg_len))));
+        const double k1p = __dadd_rn(k1, 1.0);
+        for (int tb = t0; tb < t1; tb += 64) {
+            const int nt = min(64, t1 - tb);
+            const int my = lane < nt ? q_terms[tb + lane] : -1;
+            int tf = 0;  // lane j: occurrences of query term tb + j
+            for (int64_t p = p0; p < p1; p += 64) {
+                const bool have = p + lane < p1;
+                const int dt = have ? term_ids[p + lane] : 0;
+                for (int j = 0; j < nt; ++j) {
+                    const int qt = __builtin_amdgcn_readlane(my, j);
+                    const int hits = __builtin_popcountll(__builtin_amdgcn_ballot_w64(have && dt == qt));
+                    if (lane == j) tf += hits;
+                }
+            }
+            for (int j = 0; j < nt; ++j) {  // in query order (wave-uniform values; lane 0's copy is the one kept)
+                const int qt = __builtin_amdgcn_readlane(my, j);
+                const int f = __builtin_amdgcn_readlane(tf, j);
+                if (qt < 0 || qt >= V) continue;
+                const double w = idf[qt];
+                best = __dadd_rn(best, __dmul_rn(w, k1p));
+                if (f > 0) score = __dadd_rn(score, __ddiv_rn(__dmul_rn(__dmul_rn(w, (double)f), k1p), __dadd_rn((double)f, norm)));
+            }
+        }
+    }
+    if (lane == 0) scores[pair] = best > 0.0 ? __ddiv_rn(score, best) : 0.0;
+}
+
+extern "C" int hrs_bm25_scores(hrs_ctx* ctx, hrs_postings* p, const double* idf_dev, int64_t V, double avg_len, double k1, double b,
+                               const int32_t* q_terms_dev, const int32_t* q_term_offs_dev, const int64_t* cand_rows_dev, int B,
+                               int c, double* scores_dev, void* stream) {
+    HRS_REQUIRE(ctx && p && idf_dev && q_term_offs_dev && cand_rows_dev && scores_dev, "hrs_bm25_scores: null argument");
+    HRS_REQUIRE(B >= 0 && c >= 0 && V >= 0, "hrs_bm25_scores: negative size");
+    HRS_REQUIRE(avg_len > 0.0 && k1 >= 0.0 && b >= 0.0 && b <= 1.0, "hrs_bm25_scores: avg_len=%g k1=%g b=%g", avg_len, k1, b);
+    if ((int64_t)B * c == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    const int64_t pairs = (int64_t)B * c;
+    hipLaunchKernelGGL(k_bm25_scores, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p->doc_offs,
+                       p->term_ids, p->N, p->row_offset, idf_dev, V, avg_len, k1, b, q_terms_dev, q_term_offs_dev, cand_rows_dev,
+                       B, c, scores_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
 // One block per query, one thread per candidate (c <= 256).  Python-float arithmetic: every product
 // and the sum are separately rounded fp64 operations (no contraction into an fma).
+// kw_scores (nullable): the keyword score of every candidate given directly (BM25) instead of counts / terms.
 __global__ __launch_bounds__(256) void k_fuse_sort(const float* __restrict__ dist, const int32_t* __restrict__ counts,
-                                                   const int32_t* __restrict__ q_term_offs, int c, double boost,
-                                                   int n, double* __restrict__ combined, int32_t* __restrict__ perm) {
+                                                   const int32_t* __restrict__ q_term_offs, const double* __restrict__ kw_scores,
+                                                   int c, double boost, int n, double* __restrict__ combined,
+                                                   int32_t* __restrict__ perm) {
     __shared__ double comb[256];
     __shared__ int valid[256];
     const int b = blockIdx.x, j = threadIdx.x;
@@ -71,8 +136,13 @@ __global__ __launch_bounds__(256) void k_fuse_sort(const float* __restrict__ dis
             const double d = (double)d32;
             double sem = __dsub_rn(1.0, d);
             if (!(sem > 0.0)) sem = 0.0;
-            const int m = q_term_offs[b + 1] - q_term_offs[b];
-            const double kw = m > 0 ? __ddiv_rn((double)counts[(size_t)b * c + j], (double)m) : 0.0;
+            double kw;
+            if (kw_scores) {
+                kw = kw_scores[(size_t)b * c + j];
+            } else {
+                const int m = q_term_offs[b + 1] - q_term_offs[b];
+                kw = m > 0 ? __ddiv_rn((double)counts[(size_t)b * c + j], (double)m) : 0.0;
+            }
             const double w = __dsub_rn(1.0, boost);
             mine = __dadd_rn(__dmul_rn(sem, w), __dmul_rn(kw, boost));
         }
@@ -113,7 +183,20 @@ extern "C" int hrs_fuse_sort(hrs_ctx* ctx, const float* dist_dev, const int32_t*
     if (B <= 0) return HRS_OK;
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_fuse_sort, dim3(B), dim3(256), 0, (hipStream_t)stream, dist_dev, counts_dev, q_term_offs_dev,
-                       c, boost, n, combined_dev, perm_dev);
+                       (const double*)nullptr, c, boost, n, combined_dev, perm_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+extern "C" int hrs_fuse_sort_scores(hrs_ctx* ctx, const float* dist_dev, const double* kw_scores_dev, int B, int c, double boost,
+                                    int n, double* combined_dev, int32_t* perm_dev, void* stream) {
+    HRS_REQUIRE(ctx && dist_dev && kw_scores_dev && combined_dev && perm_dev, "hrs_fuse_sort_scores: null argument");
+    HRS_REQUIRE(c >= 1 && c <= 256, "hrs_fuse_sort_scores: c=%d outside [1, 256]", c);
+    HRS_REQUIRE(n >= 1, "hrs_fuse_sort_scores: n=%d < 1", n);
+    if (B <= 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_fuse_sort, dim3(B), dim3(256), 0, (hipStream_t)stream, dist_dev, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, kw_scores_dev, c, boost, n, combined_dev, perm_dev);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }

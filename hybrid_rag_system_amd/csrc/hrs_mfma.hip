@@ -719,6 +719,9 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
             i32x4 pre[PF];
 #pragma unroll
             for (int f = 0; f < PF; ++f) pre[f] = *frag_ptr(f, 0);
+#ifdef HRS_SCAN_PROF  // the clock the chip holds in this loop: shader cycles over 100 MHz ticks
+            const uint64_t ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
             for (int64_t n = 0; n < count; ++n) {
                 const int64_t tile = tile_at(n);
                 f32xg terms;
@@ -817,6 +820,13 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
                     if (early) next_tile();
                 }
             }
+#ifdef HRS_SCAN_PROF
+            if (lane == 0 && wv == 0) {
+                unsigned long long* st = (unsigned long long*)a.prof;
+                atomicAdd(&st[4], (unsigned long long)(__builtin_amdgcn_s_memtime() - ck0));
+                atomicAdd(&st[5], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - rt0));
+            }
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         flush_wave();
@@ -1912,7 +1922,9 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.nq = bc;
         const int64_t min_len = tiles / nslices;  // shortest slice, in tiles
         int ss = (int)(min_len / 4);  // at least four sampled tiles per slice
-        if (ss > HRS_SS_MAX) ss = HRS_SS_MAX;
+        static const int ss_max = getenv("HRS_SS_MAX") ? atoi(getenv("HRS_SS_MAX")) : HRS_SS_MAX;
+        static const int j_min = getenv("HRS_J_MIN") ? atoi(getenv("HRS_J_MIN")) : HRS_J_MIN;
+        if (ss > ss_max) ss = ss_max;
         if (ss < 1) ss = 1;
         a.ss = ss;
         a.maxima = (float*)(ws + o_max);
@@ -1940,7 +1952,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.raise_limit = target * 3 / 2 < HRS_CAND_CAP_BIG / 4 ? HRS_CAND_CAP_BIG / 4
                       : (target * 3 / 2 < HRS_CAND_CAP_BIG / 2 ? target * 3 / 2 : HRS_CAND_CAP_BIG / 2);
         int j = (int)ceil((double)M * (1.0 - exp(-(double)target / ((double)ss * (double)M))));
-        if (j < HRS_J_MIN) j = HRS_J_MIN;
+        if (j < j_min) j = j_min;
         if (j > 3 * M / 4) j = 3 * M / 4;  // (the estimate of a low quantile of few maxima is a rough one)
 
         // sampled maxima -> first tau -> sampled ladder counts -> scan (tau raised where rows come in runs)

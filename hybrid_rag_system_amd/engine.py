@@ -314,6 +314,26 @@ class Engine:
         )
         return combined, perm
 
+    def bm25_scores(self, postings, idf, avg_len, q_terms, q_term_offs, cand_rows, k1=1.2, b=0.75):
+        """BM25 keyword score of every candidate, in [0, 1) (an extension; see hrs_bm25_scores): idf fp64 [V] on the GPU."""
+        if not (idf.is_cuda and idf.dtype == torch.float64 and idf.is_contiguous()):
+            raise ValueError("idf must be a contiguous float64 CUDA tensor")
+        B, c = cand_rows.shape
+        scores = torch.empty((B, c), dtype=torch.float64, device=self.device)
+        N.check(
+            N.lib().hrs_bm25_scores(self._ctx, postings._h, _ptr(idf), idf.numel(), float(avg_len), float(k1), float(b), _ptr(q_terms), _ptr(q_term_offs), _ptr(cand_rows), B, c,
+                                    _ptr(scores), _stream()),
+            "hrs_bm25_scores",
+        )
+        return scores
+
+    def fuse_sort_scores(self, dist, kw_scores, n, boost=0.3):
+        B, c = dist.shape
+        combined = torch.empty((B, n), dtype=torch.float64, device=self.device)
+        perm = torch.empty((B, n), dtype=torch.int32, device=self.device)
+        N.check(N.lib().hrs_fuse_sort_scores(self._ctx, _ptr(dist), _ptr(kw_scores), B, c, float(boost), n, _ptr(combined), _ptr(perm), _stream()), "hrs_fuse_sort_scores")
+        return combined, perm
+
     def match_counts(self, inverted, q_terms, q_term_offs, B):
         """-> uint8 [B, pitch] (pitch = rows rounded up to 4): per query, how many of its terms every row holds."""
         pitch = (inverted.n + 3) // 4 * 4
@@ -400,12 +420,18 @@ class Engine:
         N.check(N.lib().hrs_unpack_keys(self._ctx, _ptr(keys), keys.numel(), _ptr(dist), _ptr(rows), _stream()), "hrs_unpack_keys")
         return dist, rows
 
-    def hybrid_topk(self, corpus, postings, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
+    def hybrid_topk(self, corpus, postings, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto", bm25=None):
         """One pass of the hybrid path for a query batch (scripts/chromadb_helper.py:275-325 batched):
         top-2n by distance -> keyword presence counts on those 2n rows -> fused score, stable order,
-        first n.  Returns dict of GPU tensors (rows/dist of the n kept, combined, counts)."""
+        first n.  Returns dict of GPU tensors (rows/dist of the n kept, combined, counts).
+        bm25 = dict(idf=fp64 [V] CUDA tensor, avg_len=float[, k1, b]) switches the keyword score from the reference's
+        fraction of keywords present to the normalised BM25 weight (an extension): "cand_kw" then holds it."""
         c = 2 * n
         dist, rows = self.score_topk(corpus, queries, c, space=space, mode=mode)
+        if bm25 is not None:
+            kw = self.bm25_scores(postings, bm25["idf"], bm25["avg_len"], q_terms, q_term_offs, rows, bm25.get("k1", 1.2), bm25.get("b", 0.75))
+            combined, perm = self.fuse_sort_scores(dist, kw, n, boost)
+            return {"cand_dist": dist, "cand_rows": rows, "cand_kw": kw, "combined": combined, "perm": perm}
         counts = self.keyword_counts(postings, q_terms, q_term_offs, rows)
         combined, perm = self.fuse_sort(dist, counts, q_term_offs, n, boost)
         return {"cand_dist": dist, "cand_rows": rows, "cand_counts": counts, "combined": combined, "perm": perm}

@@ -40,6 +40,7 @@ extract_metadata_from_content = textproc.extract_metadata_from_content
 generate_doc_id = textproc.generate_doc_id
 extract_keywords = textproc.extract_keywords
 calculate_keyword_score = textproc.calculate_keyword_score
+bm25_keyword_score = textproc.bm25_keyword_score  # (an extension: see hybrid_query)
 
 
 def chunk_text(text, chunk_size=None, overlap=None):
@@ -98,13 +99,13 @@ def query(query_text, n_results=5, collection_name=None, where_filter=None, incl
         return {"error": str(e)}
 
 
-def _fuse(documents, metadatas, ids, distances, keywords, n_results, keyword_boost):
+def _fuse(documents, metadatas, ids, distances, keywords, n_results, keyword_boost, keyword_score=calculate_keyword_score):
     """The scoring loop, sort and cut of scripts/chromadb_helper.py:299-325 for one query."""
     scored = []
     for i, doc in enumerate(documents):
         distance = distances[i] if distances is not None else 1.0
         semantic = max(0, 1 - distance)
-        kw = calculate_keyword_score(doc, keywords)
+        kw = keyword_score(doc, keywords)
         scored.append({
             "document": doc,
             "metadata": metadatas[i] if metadatas is not None else {},
@@ -118,15 +119,27 @@ def _fuse(documents, metadatas, ids, distances, keywords, n_results, keyword_boo
     return scored[:n_results]
 
 
-def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.3, full_corpus=None):
+def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.3, full_corpus=None, keyword_scoring=None):
     """Semantic top-2n re-ranked with the keyword fraction (scripts/chromadb_helper.py:275-325).
     Like the reference it does not catch exceptions and ignores any `where` filter.
 
     full_corpus (default: the environment's HRS_HYBRID_FULL == "1", i.e. off) switches to an EXTENSION the reference
     does not have: the same fused score, but its n best over the whole collection instead of over the 2n nearest
-    rows -- a document that contains every keyword is found even when it is not among the 2n nearest."""
+    rows -- a document that contains every keyword is found even when it is not among the 2n nearest.
+
+    keyword_scoring (default: the environment's HRS_KEYWORD_SCORE, else "fraction") = "bm25" is a second EXTENSION:
+    the candidates' keyword score is textproc.bm25_keyword_score (term frequency, document length and rarity of a
+    keyword in the collection) instead of the reference's fraction of keywords present.  It applies to the re-rank of
+    the 2n nearest; with full_corpus the classes are still the reference's match counts."""
     collection = get_collection(collection_name)
     keywords = extract_keywords(query_text)
+    scoring = keyword_scoring or os.getenv("HRS_KEYWORD_SCORE") or "fraction"
+    if scoring not in ("fraction", "bm25"):
+        raise ValueError(f"keyword_scoring {scoring!r}: 'fraction' or 'bm25'")
+    keyword_score = calculate_keyword_score
+    if scoring == "bm25" and keywords:
+        df, n_docs, avg_len = collection.keyword_stats(keywords)
+        keyword_score = lambda doc, kws: bm25_keyword_score(doc, kws, df, n_docs, avg_len)
     if full_corpus is None:
         full_corpus = os.getenv("HRS_HYBRID_FULL") == "1"
     if full_corpus and keywords:
@@ -143,6 +156,7 @@ def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.
         keywords,
         n_results,
         keyword_boost,
+        keyword_score,
     )
 
 

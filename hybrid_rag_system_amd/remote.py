@@ -102,3 +102,7 @@ class RemoteCollection:
 
     def query_keyword_classes(self, query_texts, keywords, n_results=10, include=None):
         return self._client.call("query_keyword_classes", name=self.name, query_texts=list(query_texts), keywords=[list(k) for k in keywords], n_results=n_results, include=include)
+
+    def keyword_stats(self, keywords):
+        df, n, avg = self._client.call("keyword_stats", name=self.name, keywords=list(keywords))
+        return df, n, avg

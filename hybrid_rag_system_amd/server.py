@@ -55,7 +55,7 @@ def dispatch(client, req, embed=None):
     if op == "get_or_create_collection":
         col = client.get_or_create_collection(req["name"], metadata=req.get("metadata"))
         return {"name": col.name, "metadata": col.metadata}
-    if op not in ("count", "peek", "get", "add", "query", "query_keyword_classes"):
+    if op not in ("count", "peek", "get", "add", "query", "query_keyword_classes", "keyword_stats"):
         raise ValueError(f"unknown op {op!r}")
     if not isinstance(req.get("name"), str):
         raise ValueError(f"{op}: collection name missing")
@@ -72,6 +72,8 @@ def dispatch(client, req, embed=None):
             kw["embeddings"] = req["embeddings"]
         col.add(**kw)
         return None
+    if op == "keyword_stats":
+        return list(col.keyword_stats(req["keywords"]))
     if op == "query_keyword_classes":
         return col.query_keyword_classes(req["query_texts"], req["keywords"], req.get("n_results", 10), req.get("include"))
     kw = {k: req[k] for k in ("query_texts", "n_results", "include", "where", "query_embeddings") if req.get(k) is not None}

@@ -518,6 +518,22 @@ class Collection:
                 res["distances"].append([float(dist[b][j]) for j in range(len(rr))])
         return res
 
+    def keyword_stats(self, keywords):
+        """Collection statistics for the BM25 keyword weighting (an extension): ({keyword: documents that contain it
+        as a substring of their lower-cased text}, number of documents, mean document length in words).  One pass
+        over the cached lower-cased documents per keyword not seen before."""
+        n = self.count()
+        low = getattr(self, "_lower_docs", None)
+        if low is None or len(low) != n:
+            low = self._lower_docs = [(d or "").lower() for d in self.documents]
+        if getattr(self, "_kw_rows", None) != n:  # the statistics belong to this many documents
+            self._avg_words = (sum(len(d.split()) for d in low) / n) if n else 0.0
+            self._kw_df, self._kw_rows = {}, n
+        for k in keywords:
+            if k not in self._kw_df:
+                self._kw_df[k] = sum(1 for d in low if k in d)
+        return {k: self._kw_df[k] for k in keywords}, n, self._avg_words
+
     def _topk_beyond_max(self, q, k, mask):
         """More results than one scan returns (n_results is unbounded in the reference): passes of MAX_K for the
         whole batch, each resumed behind the last key every query has received (hrs_score_topk_after).  The order

@@ -134,3 +134,25 @@ def calculate_keyword_score(document, keywords):
         return 0.0
     hay = document.lower()
     return sum(1 for k in keywords if k in hay) / len(keywords)
+
+
+def bm25_keyword_score(document, keywords, doc_freq, n_docs, avg_len, k1=1.2, b=0.75):
+    """An EXTENSION (the reference has only the fraction above): the keywords weighed BM25-style and normalised to
+    [0, 1) so that it can take the fraction's place in the fused score.  tf = occurrences of the keyword as a substring
+    of the lower-cased document (the containment test of chromadb_helper.py:352-359, counted), document length in
+    whitespace-separated words, idf = ln(1 + (N - df + 0.5) / (df + 0.5)) with df = documents containing the keyword:
+      sum idf * tf * (k1 + 1) / (tf + k1 * (1 - b + b * len / avg_len))  /  sum idf * (k1 + 1)."""
+    import math
+
+    if not keywords:
+        return 0.0
+    hay = document.lower()
+    norm = k1 * ((1.0 - b) + b * (len(hay.split()) / avg_len if avg_len > 0 else 1.0))
+    score = best = 0.0
+    for k in keywords:
+        w = math.log(1.0 + (n_docs - doc_freq.get(k, 0) + 0.5) / (doc_freq.get(k, 0) + 0.5))
+        best += w * (k1 + 1.0)
+        f = hay.count(k)
+        if f > 0:
+            score += w * f * (k1 + 1.0) / (f + norm)
+    return score / best if best > 0.0 else 0.0

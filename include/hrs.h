@@ -236,6 +236,19 @@ int hrs_keyword_counts(hrs_ctx* ctx, hrs_postings* p, const int32_t* q_terms_dev
 int hrs_fuse_sort(hrs_ctx* ctx, const float* dist_dev, const int32_t* counts_dev, const int32_t* q_term_offs_dev,
                   int B, int c, double boost, int n, double* combined_dev, int32_t* perm_dev, void* stream);
 
+/* ---- BM25 keyword weighting (an extension: the reference's keyword score is the fraction above) ------ */
+/* Where calculate_keyword_score (scripts/chromadb_helper.py:352-359) counts the keywords present, this weighs them:
+ * scores_dev fp64 [B, c] = sum over query b's terms t of idf_dev[t] * tf * (k1 + 1) / (tf + k1 * (1 - b + b * len / avg_len)),
+ * divided by sum idf_dev[t] * (k1 + 1) so that it lies in [0, 1) like the fraction it replaces.  tf = occurrences of t in
+ * the candidate row's term list, len = the list's length; idf_dev fp64 [V] comes from the caller (terms outside
+ * [0, V) weigh nothing).  Every operation is a separately rounded fp64 one, in query-term order. */
+int hrs_bm25_scores(hrs_ctx* ctx, hrs_postings* p, const double* idf_dev, int64_t V, double avg_len, double k1, double b,
+                    const int32_t* q_terms_dev, const int32_t* q_term_offs_dev, const int64_t* cand_rows_dev, int B, int c,
+                    double* scores_dev, void* stream);
+/* hrs_fuse_sort with the keyword score of every candidate given (kw_scores_dev fp64 [B, c]) instead of counts / terms. */
+int hrs_fuse_sort_scores(hrs_ctx* ctx, const float* dist_dev, const double* kw_scores_dev, int B, int c, double boost, int n,
+                         double* combined_dev, int32_t* perm_dev, void* stream);
+
 /* ---- full-corpus hybrid mode (an extension: NOT what the reference computes) ------------------------ */
 /* The reference re-ranks the 2n nearest rows (scripts/chromadb_helper.py:289-325); these entry points fuse the keyword
  * fraction of scripts/chromadb_helper.py:352-359 with the semantic score over EVERY row instead, exactly: within the

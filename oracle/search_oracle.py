@@ -139,3 +139,62 @@ def hybrid_full(Q, Cm, doc_offs, term_ids, q_term_offs, q_terms, n, boost=0.3, s
     lib().hrs_oracle_hybrid_full(_p(Q), _p(Cm), C.c_int64(Cm.shape[0]), C.c_int(D), C.c_int(B), C.c_int(SPACES[space]), _p(doc_offs), _p(term_ids),
                                  _p(q_term_offs), _p(q_terms), C.c_int(n), C.c_double(boost), _p(rows), _p(comb), _p(counts), _p(dist))
     return rows, comb, counts, dist
+
+
+def bm25_idf(doc_freq, n_docs):
+    """idf of the BM25 extension: ln(1 + (N - df + 0.5) / (df + 0.5)), numpy float64 (its own definition; no reference)."""
+    df = np.asarray(doc_freq, np.float64)
+    return np.log(1.0 + (float(n_docs) - df + 0.5) / (df + 0.5))
+
+
+def bm25_scores(doc_offs, term_ids, idf, avg_len, q_term_offs, q_terms, rows, k1=1.2, b=0.75, row_offset=0):
+    """BM25 keyword score of every (query, candidate) pair, normalised to [0, 1) (an extension of
+    scripts/chromadb_helper.py:352-359, which counts presence; own semantics, parity unpinned).  Python floats: every
+    operation is one rounded fp64 operation, summed in query-term order.  rows int64 [B, c] -> fp64 [B, c]."""
+    doc_offs = np.asarray(doc_offs, np.int64)
+    term_ids = np.asarray(term_ids, np.int32)
+    idf = np.asarray(idf, np.float64)
+    rows = np.asarray(rows, np.int64)
+    B, c = rows.shape
+    out = np.zeros((B, c), np.float64)
+    n_rows = len(doc_offs) - 1
+    k1, b, avg_len = float(k1), float(b), float(avg_len)
+    for q in range(B):
+        terms = [int(t) for t in q_terms[q_term_offs[q] : q_term_offs[q + 1]]]
+        for j in range(c):
+            r = int(rows[q, j]) - row_offset
+            if rows[q, j] < 0 or r < 0 or r >= n_rows:
+                continue
+            lst = term_ids[doc_offs[r] : doc_offs[r + 1]].tolist()
+            norm = k1 * ((1.0 - b) + b * (float(len(lst)) / avg_len))
+            score = best = 0.0
+            for t in terms:
+                if t < 0 or t >= len(idf):
+                    continue
+                w = float(idf[t])
+                best = best + w * (k1 + 1.0)
+                f = lst.count(t)
+                if f > 0:
+                    score = score + ((w * float(f)) * (k1 + 1.0)) / (float(f) + norm)
+            out[q, j] = score / best if best > 0.0 else 0.0
+    return out
+
+
+def fuse_sort_scores(dist, kw, n, boost=0.3):
+    """The fusion and stable order of scripts/chromadb_helper.py:302-325 with the keyword score given per candidate
+    (Python floats) -> combined fp64 [B, n] (-1 where missing), perm int32 [B, n] (-1)."""
+    dist = np.asarray(dist, np.float32)
+    B, c = dist.shape
+    comb = np.full((B, n), -1.0, np.float64)
+    perm = np.full((B, n), -1, np.int32)
+    for q in range(B):
+        scored = []
+        for j in range(c):
+            if np.isinf(dist[q, j]):
+                continue
+            sem = max(0.0, 1.0 - float(dist[q, j]))
+            scored.append((sem * (1.0 - boost) + float(kw[q, j]) * boost, j))
+        scored.sort(key=lambda x: x[0], reverse=True)  # stable
+        for i, (v, j) in enumerate(scored[:n]):
+            comb[q, i], perm[q, i] = v, j
+    return comb, perm

@@ -233,3 +233,38 @@ def test_full_corpus_hybrid_flag_on_the_text_path(helper, monkeypatch):
         monkeypatch.delenv("HRS_HYBRID_FULL")
         assert helper.hybrid_query(q, 5, "cfg1") == plain  # the default stays the reference's re-rank
     assert differs >= 1  # somewhere a keyword match lies outside the 2n nearest rows
+
+
+def test_bm25_keyword_scoring_on_the_text_path(helper, monkeypatch):
+    """keyword_scoring="bm25" / HRS_KEYWORD_SCORE=bm25 (an extension; off by default): the re-rank of the 2n nearest
+    with the candidates' keyword score from textproc.bm25_keyword_score over the collection's own statistics -- equal
+    to that arithmetic applied to the plain query's candidates; the default stays the reference's fraction."""
+    from hybrid_rag_system_amd import textproc
+
+    if helper.get_collection("cfg1").count() == 0:
+        helper.index_directory(CORPUS_DIR, ["*.md"], "cfg1")
+    col = helper.get_collection("cfg1")
+    low = [d.lower() for d in col.documents]
+    avg = sum(len(d.split()) for d in low) / len(low)
+    changed = 0
+    for q in QUERIES + ["docker compose volumes backup"]:
+        kws = helper.extract_keywords(q)
+        res = col.query(query_texts=[q], n_results=10, include=["documents", "metadatas", "distances"])
+        df = {k: sum(1 for d in low if k in d) for k in kws}
+        scored = []
+        for doc, meta, id_, dist in zip(res["documents"][0], res["metadatas"][0], res["ids"][0], res["distances"][0]):
+            sem = max(0, 1 - dist)
+            kw = textproc.bm25_keyword_score(doc, kws, df, len(low), avg)
+            scored.append({"document": doc, "metadata": meta, "id": id_, "semantic_score": sem, "keyword_score": kw, "combined_score": sem * 0.7 + kw * 0.3, "distance": dist})
+        scored.sort(key=lambda r: r["combined_score"], reverse=True)
+        got = helper.hybrid_query(q, 5, "cfg1", keyword_scoring="bm25")
+        assert got == scored[:5], q
+        plain = helper.hybrid_query(q, 5, "cfg1")
+        changed += [g["keyword_score"] for g in got] != [p["keyword_score"] for p in plain]
+        monkeypatch.setenv("HRS_KEYWORD_SCORE", "bm25")
+        assert helper.hybrid_query(q, 5, "cfg1") == got
+        monkeypatch.delenv("HRS_KEYWORD_SCORE")
+        assert helper.hybrid_query(q, 5, "cfg1") == plain
+    assert changed >= 1
+    with pytest.raises(ValueError):
+        helper.hybrid_query("x y z", 5, "cfg1", keyword_scoring="tfidf")

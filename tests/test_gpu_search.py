@@ -816,3 +816,50 @@ def test_topk_by_classes_in_one_pass(eng, space, n, d, b, k, levels):
             want = so.topk_keys(Q[q : q + 1], C, k, space, row_offset=off, mask=(cls[q, :n] == l).astype(np.uint8))
             assert np.array_equal(got[q, l], want[0]), (q, l)
     corpus.close()
+
+
+def test_bm25_keyword_scores_and_fusion(eng):
+    """The BM25 keyword weighting (an extension with its own semantics: parity unpinned): hrs_bm25_scores and
+    hrs_fuse_sort_scores against the oracle's Python-float restatement, bit for bit -- ragged term lists with repeated
+    terms, empty rows, queries without terms, terms outside the vocabulary, rows outside the shard, missing candidates."""
+    rng = np.random.default_rng(77)
+    n, V, B, c = 5000, 400, 37, 20
+    p = 1.0 / np.arange(1, V + 1)
+    p /= p.sum()
+    lens = rng.integers(0, 150, n)
+    lens[:5] = 0
+    lists = [rng.choice(V, int(l), replace=True, p=p).astype(np.int32) for l in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    terms = np.concatenate(lists + [np.empty(0, np.int32)]).astype(np.int32)
+    df = np.zeros(V, np.int64)
+    for l in lists:
+        df[np.unique(l)] += 1
+    idf = so.bm25_idf(df, n)
+    avg_len = float(lens.mean())
+    m = rng.integers(0, 9, B)
+    m[1] = 70  # more terms than a wave has lanes
+    qoffs = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms = np.concatenate([rng.choice(V, int(mm), replace=True, p=p) for mm in m] + [np.empty(0, np.int64)]).astype(np.int32)
+    qterms[qoffs[2]] = -7       # ignored
+    qterms[qoffs[3]] = V + 3    # ignored
+    off = 1000
+    rows = rng.integers(off, off + n, (B, c)).astype(np.int64)
+    rows[0, :5] = off + np.arange(5)  # empty rows
+    rows[4, 3] = -1
+    rows[4, 4] = off - 1
+    rows[4, 5] = off + n
+    want = so.bm25_scores(offs, terms, idf, avg_len, qoffs, qterms, rows, row_offset=off)
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda(), row_offset=off)
+    got = eng.bm25_scores(post, torch.from_numpy(idf).cuda(), avg_len, torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda(), torch.from_numpy(rows).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    assert (want >= 0).all() and (want < 1).all() and (want > 0).any()
+    dist = np.sort(rng.random((B, c)).astype(np.float32) * 1.3, axis=1)
+    dist[4, 15:] = np.inf
+    dist[7, 3] = dist[7, 2]
+    wc, wp = so.fuse_sort_scores(dist, want, 10, 0.3)
+    gc, gp = eng.fuse_sort_scores(torch.from_numpy(dist).cuda(), got, 10, 0.3)
+    torch.cuda.synchronize()
+    assert np.array_equal(gp.cpu().numpy(), wp)
+    assert np.array_equal(gc.cpu().numpy().view(np.uint64), wc.view(np.uint64))
+    post.close()

@@ -242,3 +242,20 @@ def test_chunk_document_matches_the_reference():
         assert len(got) == want[name]["n"], name
         assert [len(c) for c in got] == want[name]["lens"], name
         assert [hashlib.sha256(c.encode()).hexdigest()[:16] for c in got] == want[name]["sha"], name
+
+
+def test_bm25_keyword_score_properties():
+    """The BM25 keyword weighting (an extension; the reference's score is the fraction): in [0, 1), zero without a
+    match, grows with the term frequency, falls with the document's length, and a rare keyword outweighs a common one."""
+    from hybrid_rag_system_amd.textproc import bm25_keyword_score, calculate_keyword_score
+
+    df, n, avg = {"proxmox": 3, "server": 400, "backup": 50}, 1000, 100.0
+    kws = ["proxmox", "server", "backup"]
+    s = lambda doc: bm25_keyword_score(doc, kws, df, n, avg)
+    assert s("nothing relevant here") == 0.0 and bm25_keyword_score("proxmox", [], df, n, avg) == 0.0
+    one, two = s("the proxmox host"), s("the proxmox host runs proxmox")
+    assert 0.0 < one < two < 1.0
+    assert s("proxmox " + "filler " * 400) < one
+    assert s("a proxmox") > s("a server")  # rarity
+    assert calculate_keyword_score("a Proxmox SERVER", kws) == 2 / 3  # the reference's fraction is untouched
+    assert 0.0 < s("Proxmox SERVER backup " * 50) < 1.0

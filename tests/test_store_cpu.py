@@ -106,3 +106,18 @@ def test_collection_names_that_could_leave_the_data_directory_are_refused(tmp_pa
 def test_valid_names():
     for name in ("infrastructure_docs", "homelab_knowledge", "cfg1", "a.b-c_d", "x" * 63):
         assert validate_name(name) == name
+
+
+def test_keyword_stats_follow_the_collection(tmp_path):
+    """Collection.keyword_stats (behind the BM25 extension): document frequency by substring of the lower-cased
+    text, mean length in words, refreshed when documents are added."""
+    from hybrid_rag_system_amd import store
+
+    col = store.Collection.__new__(store.Collection)
+    col.documents = ["The Proxmox host", "proxmox PROXMOX backup", "nothing"]
+    col.count = lambda: len(col.documents)
+    df, n, avg = col.keyword_stats(["proxmox", "backup", "zfs"])
+    assert (df, n) == ({"proxmox": 2, "backup": 1, "zfs": 0}, 3) and avg == (3 + 3 + 1) / 3
+    col.documents.append("zfs pool on proxmox")
+    df, n, avg = col.keyword_stats(["proxmox", "zfs"])
+    assert (df, n) == ({"proxmox": 3, "zfs": 1}, 4) and avg == (3 + 3 + 1 + 4) / 4
