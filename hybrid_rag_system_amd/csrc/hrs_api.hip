@@ -388,7 +388,7 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     {
         int64_t g[16];
         HRS_CHECK_HIP(hipMemcpy(g, ctx->stats_dev, sizeof(g), hipMemcpyDeviceToHost));
-        if (g[5] > 0 && g[6] == 0)  // the 16 x 16 x 64 main pass stamps cycles and 100 MHz ticks around its loop
+        if (g[5] > 0)  // (meaningful when the main pass was the 16 x 16 x 64 one:) it stamps cycles and 100 MHz ticks around its loop
             fprintf(stderr, "main pass (16x16x64): clock in the loop %.3f GHz, loop %.1f us per workgroup\n", (double)g[4] / (double)g[5] * 0.1, g[5] / 256.0 / 100.0);
         fprintf(stderr, "scan per WG (us): prologue %.2f first-tile %.2f loop %.2f flush %.2f | start skew %.2f, first loop end after %.2f, last end after %.2f\n",
                 g[4] / 25600.0, g[5] / 25600.0, g[6] / 25600.0, g[7] / 25600.0, (g[9] - g[8]) / 100.0, (g[10] - g[8]) / 100.0, (g[11] - g[8]) / 100.0);
@@ -398,7 +398,7 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     {
         int64_t g[16];
         HRS_CHECK_HIP(hipMemcpy(g, ctx->stats_dev, sizeof(g), hipMemcpyDeviceToHost));
-        fprintf(stderr, "select: init %lld resc %lld total %lld (x10 ns, summed over queries) rounds %lld maxcand %lld\n", (long long)g[12], (long long)g[13], (long long)g[14], (long long)g[15], (long long)h[1]);
+        fprintf(stderr, "select: init %lld (list load %lld, sort %lld) resc %lld total %lld (x10 ns, summed over queries) rounds %lld maxcand %lld\n", (long long)g[12], (long long)g[6], (long long)g[7], (long long)g[13], (long long)g[14], (long long)g[15], (long long)h[1]);
     }
 #endif
     return HRS_OK;

@@ -1511,10 +1511,6 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
 #endif
     int n2 = 256;
     while (n2 < c) n2 <<= 1;
-    for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP_BIG + t] : HRS_PAD_KEY;
-    for (int t = tid; t < RMAX; t += 256) ek[t] = HRS_PAD_KEY;
-    const float* qr = a.Q + (size_t)q * a.D;
-    for (int t = tid; t < a.D; t += 256) qs[t] = qr[t];
     auto sort_keys = [&](uint64_t* p, int n) __attribute__((always_inline)) {
         if (n <= 2048) {
             bitonic_sort_u64_256t(p, n, tid);
@@ -1526,7 +1522,135 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
             bitonic_sort_u64_regs<32>(p, tid);
         }
     };
-    sort_keys(s, n2);
+    // first round: the rows that must be re-scored for a proof are those whose recorded bound reaches the k-th best
+    // exact score -- for the int8 shadow several times k, rarely more than 8 k + 48 (the launcher's first_rows)
+    int first = a.first_rows;
+    // The first round needs the `first` best candidates by recorded score as a SET, in no order, and nearly every
+    // query is settled by it: instead of sorting the list, the small variant bins the recorded scores (1024 bins over
+    // their range, in LDS), takes the bins that together hold at most `first` candidates, and moves those to the
+    // front of the list.  A candidate's bin rises with its key, so the front is a prefix of the sorted order; the list
+    // is sorted only if a second round turns out to be needed (sorted == false until then).
+    bool sorted = true;
+    int want = c < first ? c : first;
+    const float* qr = a.Q + (size_t)q * a.D;
+    for (int t = tid; t < a.D; t += 256) qs[t] = qr[t];
+    if (!BIG && c > 0) {
+        constexpr int KPT = SCAP / 256;
+        uint64_t kk[KPT];
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+            kk[u] = HRS_PAD_KEY;
+            if (u * 256 < c) {
+                const int t = tid + u * 256;
+                if (t < c) {
+                    kk[u] = a.cand[(size_t)ql * HRS_CAND_CAP_BIG + t];
+                    lo = min(lo, (uint32_t)(kk[u] >> 32));
+                    hi = max(hi, (uint32_t)(kk[u] >> 32));
+                }
+            }
+        }
+        int* hist = (int*)ek;  // [1024] bins, then [1024] their running sums; ek itself is filled further down
+        uint32_t* ctl = (uint32_t*)(hist + 1024);  // [0] lowest, [1] highest recorded score, [2] last bin taken + 1, [3] front, [4] back
+        for (int t = tid; t < 1024; t += 256) hist[t] = 0;
+        if (tid == 0) {
+            ctl[0] = 0xFFFFFFFFu;
+            ctl[1] = 0u;
+            ctl[2] = 0u;
+            ctl[3] = 0u;
+            ctl[4] = 0u;
+        }
+        __syncthreads();
+        if (c > first) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {  // one atomic per wave, not per thread
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+            }
+            if ((tid & 63) == 0) {
+                atomicMin(&ctl[0], lo);
+                atomicMax(&ctl[1], hi);
+            }
+            __syncthreads();
+            const uint32_t base = ctl[0];
+            const float scale = 1023.0f / (float)max(ctl[1] - base, 1u);
+            int bin[KPT];
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) {
+                bin[u] = min(1023, (int)((float)((uint32_t)(kk[u] >> 32) - base) * scale));
+                if (u * 256 < c && tid + u * 256 < c) atomicAdd(&hist[bin[u]], 1);
+            }
+            __syncthreads();
+            // running sums of the bins (thread t: bins 4 t .. 4 t + 3); the last bin whose running sum is at most `first`
+            int h4[4], run = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h4[i] = hist[4 * tid + i];
+                run += h4[i];
+            }
+            int incl = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if ((tid & 63) >= d) incl += o;
+            }
+            int* wsum = hist + 1024;  // (behind ctl: [8..12))
+            if ((tid & 63) == 63) wsum[8 + (tid >> 6)] = incl;
+            __syncthreads();
+            int before = incl - run;
+            for (int w = 0; w < (tid >> 6); ++w) before += wsum[8 + w];
+            int cum = before;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int prev = cum;
+                cum += h4[i];
+                if (prev <= first && cum > first) {  // exactly one (bin, thread): c > first
+                    ctl[2] = (uint32_t)(4 * tid + i);  // bins below this one are taken
+                    ctl[4] = (uint32_t)prev;           // ... they hold this many candidates
+                }
+            }
+            __syncthreads();
+            const int take = (int)ctl[2], front_n = (int)ctl[4];
+            if (front_n >= first / 2) {
+                // partition in place: every key is in a register by now
+                __syncthreads();
+                if (tid == 0) ctl[4] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < KPT; ++u) {
+                    if (u * 256 < c && tid + u * 256 < c) {
+                        const bool fr = bin[u] < take;
+                        const int pos = fr ? (int)atomicAdd(&ctl[3], 1u) : front_n + (int)atomicAdd(&ctl[4], 1u);
+                        s[pos] = kk[u];
+                    }
+                }
+                want = front_n;
+                sorted = false;
+            } else {
+                // (scores bunched into one bin -- runs of equal rows: the sorted list serves)
+#pragma unroll
+                for (int u = 0; u < KPT; ++u) s[tid + u * 256] = kk[u];
+            }
+        } else {
+            // every candidate is re-scored in the first round: no order is needed at all
+#pragma unroll
+            for (int u = 0; u < KPT; ++u)
+                if (u * 256 < c && tid + u * 256 < c) s[tid + u * 256] = kk[u];
+            sorted = false;
+        }
+        __syncthreads();
+    } else {
+        for (int t = tid; t < n2; t += 256) s[t] = t < c ? a.cand[(size_t)ql * HRS_CAND_CAP_BIG + t] : HRS_PAD_KEY;
+    }
+    for (int t = tid; t < RMAX; t += 256) ek[t] = HRS_PAD_KEY;
+#ifdef HRS_SEL_PROF
+    __syncthreads();
+    const long long pt_load = wall_clock64() - pt0;
+#endif
+    if (sorted) sort_keys(s, n2);
+#ifdef HRS_SEL_PROF
+    pt_sort = wall_clock64() - pt0 - pt_load;
+#endif
 
     const double qn = a.qn2[ql], ncmin = a.norm_stats[0], ncmax = a.norm_stats[1];
     const double sq = a.qscale ? (double)a.qscale[ql] : 1.0;
@@ -1560,11 +1684,8 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
         for (; d0 < a.D; ++d0) nq = fma((double)qs[d0], (double)qs[d0], nq);
     }
     int done = 0;                       // candidates [0, done) are re-scored
-    // first round: the rows that must be re-scored for a proof are those whose recorded bound reaches the k-th best
-    // exact score -- for the int8 shadow several times k, rarely more than 8 k + 48
-    int first = a.first_rows;
-    int want = c < first ? c : first;
     bool accept = false, defer = false;
+    uint64_t* top = ek;                 // where the re-scored keys stand sorted
 #ifdef HRS_SEL_PROF
     const long long pt_init = wall_clock64() - pt0;
 #endif
@@ -1674,24 +1795,56 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
 #endif
         done = want;
         if (tid == 0) need_s = 0;
-        {
+        if (done <= 256) {
+            // one re-scored key per thread: its rank among them by counting (keys are distinct), the sorted copy in
+            // the second wave's staging block (free between rounds)
+            __syncthreads();
+            top = (uint64_t*)(stage + 64 * 144);
+            const uint64_t mykey = tid < done ? ek[tid] : HRS_PAD_KEY;
+            int rank = 0;
+            for (int u = 0; u < done; ++u) rank += ek[u] < mykey;
+            if (tid < done) top[rank] = mykey;
+            __syncthreads();
+        } else {
             int en = 256;
             while (en < done) en <<= 1;
             sort_keys(ek, en);  // (its barriers also publish need_s)
+            top = ek;
         }
         if (overflow || done < a.k) break;
-        const double dk = (double)orderable_f32((uint32_t)(ek[a.k - 1] >> 32));
-        // recorded scores are sorted descending, so the candidates that could still beat dk are a prefix
-        int mine = 0;
-        for (int t = tid; t < c; t += 256) {
-            const float A = orderable_f32(~(uint32_t)(s[t] >> 32));
+        const double dk = (double)orderable_f32((uint32_t)(top[a.k - 1] >> 32));
+        auto could_beat = [&](uint64_t key) -> bool {
+            const float A = orderable_f32(~(uint32_t)(key >> 32));
             const double dmin = dist_floor(A);
-            if (!(dk + 1e-6 * (1.0 + fabs(dmin)) < dmin)) mine = t + 1;
+            return !(dk + 1e-6 * (1.0 + fabs(dmin)) < dmin);
+        };
+        if (!sorted) {
+            // the list is partitioned, not sorted: is any candidate behind the re-scored front still in the race?
+            int bad = 0;
+            for (int t = done + tid; t < c; t += 256) bad |= could_beat(s[t]);
+            if (bad) need_s = 1;
+            __syncthreads();
+            const int more = need_s;
+            __syncthreads();
+            if (more) {  // a second round: from here on the list is sorted (its first `done` are the re-scored ones)
+                for (int t = c + tid; t < n2; t += 256) s[t] = HRS_PAD_KEY;
+                sort_keys(s, n2);
+                sorted = true;
+                if (tid == 0) need_s = 0;
+                __syncthreads();
+            }
         }
-        if (mine) atomicMax(&need_s, mine);
-        __syncthreads();
-        const int need = need_s;
-        __syncthreads();
+        int need = done;
+        if (sorted) {
+            // recorded scores are sorted descending, so the candidates that could still beat dk are a prefix
+            int mine = 0;
+            for (int t = tid; t < c; t += 256)
+                if (could_beat(s[t])) mine = t + 1;
+            if (mine) atomicMax(&need_s, mine);
+            __syncthreads();
+            need = need_s;
+            __syncthreads();
+        }
         if (need <= done) {
             // and nothing that was never recorded (score <= tau) may beat it either
             const double dmin = dist_floor(a.tau[ql]);
@@ -1711,6 +1864,8 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
         atomicAdd((unsigned long long*)&a.stats[13], (unsigned long long)pt_resc);
         atomicAdd((unsigned long long*)&a.stats[14], (unsigned long long)(wall_clock64() - pt0));
         atomicAdd((unsigned long long*)&a.stats[15], (unsigned long long)pt_rounds);
+        atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)pt_load);
+        atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)pt_sort);
     }
 #endif
     if (tid == 0) {
@@ -1729,7 +1884,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
     __syncthreads();
     if (ok)
         for (int t = tid; t < a.k; t += 256) {
-            const uint64_t key = ek[t];
+            const uint64_t key = top[t];
             a.keys_out[(size_t)q * a.k + t] = key;
             hrs_store_unpacked(key, (size_t)q * a.k + t, a.dist_out, a.rows_out);
         }
