@@ -1,16 +1,21 @@
 // MiniLM-class sentence encoder on the matrix cores (replaces the CPU torch forward that
 // sentence-transformers runs behind SentenceTransformerEmbeddingFunction, scripts/chromadb_helper.py:58-71).
 //
-//   k_embed_ln      word + position + type embedding gather, LayerNorm            -> x   bf16 [M, H]
+// No LayerNorm kernel runs.  A block's output is stored un-normalised (bf16 z) together with per-row sums of the
+// STORED values; whoever reads z applies the LayerNorm: a projection by linearity in its epilogue,
+//   LN(z) W^T + b = rstd (z (W gamma)^T) - rstd mean colsum(W gamma) + (W beta + b)
+// (k_fold_ln prepares W gamma, its column sums and W beta + b when the weights are loaded; rows carry
+// (rstd, -mean rstd)), a residual add by normalising the value it adds.
+//
+//   k_embed_sum          word + position + type embedding gather              -> z bf16 [M, H], row sums
 //   per layer:
-//   k_gemm<QKV>     x @ Wqkv^T + b; Q (pre-scaled) and K head-major, V in MFMA-fragment order
-//   k_attention     per (sequence, head): S = K Q^T in registers (S <= 256), masked softmax, O = P V
-//   k_gemm<RESID>   ctx @ Wo^T + b + x                                            -> pre-LN bf16
-//   k_layernorm                                                                   -> y   bf16
-//   k_gemm<GELU>    gelu(y @ Wi^T + b)                                            -> h   bf16 [M, I]
-//   k_gemm<RESID>   h @ Wd^T + b + y                                              -> pre-LN bf16
-//   k_layernorm                                                                   -> x
-//   k_pool_norm     masked mean over tokens, L2 normalise                         -> out fp32 [B, H]
+//   k_gemm_ws<QKV>       LN(z) @ Wqkv^T + b; Q (pre-scaled) and K in MFMA operand order, V in fragment order
+//   k_attention          per (sequence, head): S = K Q^T in registers (S <= 256), masked softmax, O = P V
+//   k_gemm_ws<LN>        LN(ctx @ Wo^T + b + LN(z))                            -> y bf16 (normalised: the FFN reads it thrice)
+//   k_gemm_ws<GELU>      gelu(y @ Wi^T + b)                                    -> h bf16 [M, I], down projection's operand order
+//   k_gemm_down          h @ Wd^T + b + y                                      -> z bf16, row sums
+//   k_pool_norm          LN of the last z per token, masked mean, L2 normalise -> out fp32 [B, H]
+// (FFN widths other than 1536 take the generic k_gemm below with k_row_stats behind it.)
 //
 // GEMM: C[M,N] = A[M,K] W[N,K]^T, bf16 in, fp32 accumulate (v_mfma_f32_32x32x16_bf16). Persistent
 // workgroups of 8 waves walk 256x192 output tiles; K advances in 64-wide stages that arrive in LDS
