@@ -997,6 +997,7 @@ struct AttnArgs {
 // Two waves per SIMD are asked for so that the register budget is 256: the compiler then keeps the MFMA
 // results in ordinary registers (with a 512-register budget it puts them in the accumulator half and
 // copies every score tile out and every initial value in, 26 register moves per MFMA here).
+#define ATT_NOSHIFT_BOUND 100.0f  // |q| |k| up to which the scores go through exp2 unshifted
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
     // K and V of this (sequence, head), both stored by the QKV projection in the order the MFMAs take them
@@ -1022,6 +1023,28 @@ __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
     }
     __syncthreads();
     const int koff0 = lane * 16, koff1 = 1024 + lane * 16;  // the two k-steps of a key tile: lane-linear, conflict-free
+    // The largest key norm of this (sequence, head): |q . k| <= |q| |k| bounds every score of a query without computing
+    // one.  Where that bound is small enough for exp2 to take the scores as they are -- it nearly always is: scores are
+    // in units of log2 e / sqrt(32) -- the row maximum is not needed and pass 1 below is skipped (softmax is invariant
+    // under the shift; P = 2^s stays within 2^+-100, its sum over 256 keys and its products with V within fp32).
+    __shared__ float kmax_w[4];
+    {
+        float k2 = 0.f;
+        if (tid < nkt * 32) {  // thread <-> key: its 32 values are four 16-byte pieces of the operand order
+            const int kt = tid >> 5, j = tid & 31;
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const bf16x8 kv = *(const bf16x8*)(klds + ((kt * 2 + (pc >> 1)) * 64 + j + 32 * (pc & 1)) * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) k2 = fmaf((float)kv[e], (float)kv[e], k2);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, d));
+        if (lane == 0) kmax_w[wv] = k2;
+    }
+    __syncthreads();
+    const float kmax2 = fmaxf(fmaxf(kmax_w[0], kmax_w[1]), fmaxf(kmax_w[2], kmax_w[3]));
 
     for (int qt = wv; qt < NKT; qt += 4) {
         // the key masks of a partial tile are recomputed where they are used: hoisted out of this loop they
@@ -1030,12 +1053,23 @@ __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
         bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qb + ((qt * 2 + ks) * 64 + lane) * 16);
-        // pass 1: row maximum.  Scores are recomputed in pass 2 (two MFMAs per tile) instead of keeping
-        // the 256-wide row in registers, which would leave one wave per SIMD and no latency hiding.
-        float m = -1e30f;
+        // this lane's query: half of its 32 values are here, the other half on lane ^ 32
+        float q2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q2 = fmaf((float)qf[ks][e], (float)qf[ks][e], q2);
+        q2 += __shfl_xor(q2, 32);
+        float bound2 = q2 * kmax2;  // (|q| |k|)^2 of the tile's largest query
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) bound2 = fmaxf(bound2, __shfl_xor(bound2, d));
+        const bool shifted = !(__builtin_amdgcn_readfirstlane(__float_as_int(bound2)) <= __float_as_int(ATT_NOSHIFT_BOUND * ATT_NOSHIFT_BOUND));
+        // pass 1 (only where the bound does not settle it): row maximum.  Scores are recomputed in pass 2 (two MFMAs per
+        // tile) instead of keeping the 256-wide row in registers, which would leave one wave per SIMD and no latency hiding.
+        float m = shifted ? -1e30f : 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            if (kt < nkt) {
+            if (shifted && kt < nkt) {
                 f32x16 sc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = 0.f;
@@ -1052,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(AttnArgs a) {
             }
         }
         m = fmaxf(m, __shfl_xor(m, 32));
-        // pass 2: the accumulator starts at -m, so the MFMA result is already s - m
+        // pass 2: the accumulator starts at -m (0 without pass 1), so the MFMA result is already s - m
         float l = 0.f;
         f32x16 o, negm;
 #pragma unroll

@@ -102,3 +102,26 @@ def test_encoder_matches_transformers_goldens(setup, golden_dir):
     want = g["embeddings"]
     cos = (want * got).sum(1) / (np.linalg.norm(want, axis=1) * np.linalg.norm(got, axis=1))
     assert cos.min() >= COS_TOL, cos
+
+
+@pytest.mark.parametrize("gain", [7.0, 12.0])  # |q| |k| up to about 2.1 gain^2: around the limit, and far beyond it
+def test_attention_with_large_scores_takes_the_row_maximum(setup, gain):
+    """The attention kernel skips its row-maximum pass where |q| |k| bounds the scores below 2^100 (every case above:
+    the generated weights score within +-2).  Query and key projections scaled up make the bound exceed that for some
+    or all query tiles (gain^2 times the scores: softmax rows close to one-hot), so both forms run, side by side in one
+    launch for the smaller gain; the result must stay with the oracle's."""
+    eng, enc, w, cfg = setup
+    w2 = dict(w)
+    for l in range(cfg.layers):
+        for n in ("q_w", "q_b", "k_w", "k_b"):
+            w2[f"l{l}.{n}"] = np.asarray(w[f"l{l}.{n}"]) * gain
+    enc2 = eng.encoder(w2, cfg)
+    ids, lens = _inputs(12, 128, seed=int(gain))
+    want = EO.forward(w2, ids, lens, cfg).numpy()
+    got = enc2.encode_ids(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    enc2.close()
+    assert np.isfinite(got).all()
+    cos = (got * want).sum(1)
+    assert cos.min() >= COS_TOL, cos
