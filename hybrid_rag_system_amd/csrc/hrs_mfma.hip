@@ -1746,7 +1746,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
             // costs about one memory latency instead of one per chunk.  No request is conditional -- a piece beyond
             // the row's end is replaced by the row's last piece, which nobody reads back -- so the loop body has no
             // branch around a load and the compiler's waits stay counted.
-            constexpr int SEL_PF = 4;
+            constexpr int SEL_PF = 3;
             const int nchunk = (a.D + 31) >> 5;
             const int last_piece = a.D * 4 - 16;
             f32x4 nxt[SEL_PF][8];
@@ -2080,6 +2080,9 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         static const int ss_max = getenv("HRS_SS_MAX") ? atoi(getenv("HRS_SS_MAX")) : HRS_SS_MAX;
         static const int j_min = getenv("HRS_J_MIN") ? atoi(getenv("HRS_J_MIN")) : HRS_J_MIN;
         if (ss > ss_max) ss = ss_max;
+        // short slices (a shard of a split corpus): the sample is cheap against the rows its coarseness makes the main
+        // pass record, which cost the same whatever the corpus' size
+        if (min_len < 400 && ss > 24) ss = 24;
         if (ss < 1) ss = 1;
         a.ss = ss;
         a.maxima = (float*)(ws + o_max);

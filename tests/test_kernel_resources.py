@@ -206,3 +206,15 @@ def test_encoder_gemms_with_counted_waits_do_not_spill(tmp_path):
     assert len(ks) >= 4
     for name, k in ks.items():
         assert int(k["vgpr_spill_count"]) == 0 and int(k["private_segment_fixed_size"]) == 0, (name, k)
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
+def test_small_rescore_kernel_fits_two_workgroups_without_spilling(tmp_path):
+    """The small instance of the re-score kernel runs two workgroups per CU (256 registers per wave).  With a four-deep
+    window of row pieces in registers it needed more, spilled 8 to 25 registers into the loop that waits for those very
+    loads, and ran a tenth slower than with a three-deep one that fits."""
+    ks = {n: k for n, k in _metadata("hrs_mfma.hip", tmp_path).items() if "k_select_rescore" in n and n.endswith("ELb0EEv10SelectArgs")}
+    assert len(ks) == 3
+    for name, k in ks.items():
+        assert int(k["vgpr_count"]) <= 256, (name, k)
+        assert int(k["vgpr_spill_count"]) == 0 and int(k["private_segment_fixed_size"]) == 0, (name, k)
