@@ -577,16 +577,19 @@ __device__ __forceinline__ size_t qfrag16_offset(int q, int c, int k64) {  // by
     return ((size_t)(q >> 4) * k64 + (c >> 6)) * 1024 + ((c >> 4) & 3) * 256 + (q & 15) * 16 + (c & 15);
 }
 
-template <int KS>
+// QG: 16-query operands per wave (4 up to depth 384, 2 beyond: the fragments of 32 queries x 1024 depth are 128
+// registers); TR: rows per tile (64, or 32 where four tiles of 64 rows would not fit the LDS).
+template <int KS, int QG, int TR>
 __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __restrict__ qb16) {
-    constexpr int TR = 64, NW = 8, QG = 4, K64 = KS / 2;
-    constexpr int RB = KS * 32, TILE_BYTES = TR * RB, NBUF = 4, IPW = TR * KS / (32 * NW), NSUB = 2;
+    constexpr int NW = 8, K64 = KS / 2;
+    constexpr int RB = KS * 32, TILE_BYTES = TR * RB, NBUF = 4, IPW = TR * KS / (32 * NW), NSUB = TR / 32;
     constexpr int STG = scan_stage(true), PPR = 2 * KS;
     constexpr int SWB = (PPR % 16 == 0) ? 4 : 3;
     constexpr int NB = 1 << (SWB - 2);   // per-lane fragment bases: k-steps NB apart differ by an immediate
     constexpr int FSTEP = 16 << SWB;
     constexpr int NF = 2 * K64;          // fragments per 32-row group: (k-step, row half)
-    static_assert(KS % 2 == 0 && KS <= 12 && PPR % 8 == 0, "depth up to 384 in steps of 64");
+    static_assert(KS % 2 == 0 && PPR % 8 == 0 && (TR == 32 || TR == 64) && QG * K64 * 4 <= 128 && NBUF * TILE_BYTES <= 128 * 1024,
+                  "depth in steps of 64; query fragments within 128 registers; four tiles within 128 KB");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
     const int qg = loc % a.nqg;
     const int nslices = HRS_NUM_CU / a.nqg;
     const int slice = xcd * (32 / a.nqg) + loc / a.nqg;
-    const int q0 = qg * (MF_QPB * 2) + wv * 64;
+    const int q0 = qg * (NW * QG * 16) + wv * (QG * 16);
 
     i32x4 qf[QG][K64];
     float taum[QG];
@@ -685,10 +688,13 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
         typedef const __attribute__((address_space(3))) char* lds_cptr;
         typedef const __attribute__((address_space(3))) i32x4* lds_frag;
         constexpr int PF = 4 < NF ? 4 : NF;
-        typedef float f32xg __attribute__((ext_vector_type(8)));
+        typedef float f32xg __attribute__((ext_vector_type(4 * NSUB)));
         auto terms_request = [&](int64_t tile, f32xg& dst) __attribute__((always_inline)) {
             const char* p = uniform_ptr(a.group + tile * NSUB);
-            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst) : "s"(p));
+            if constexpr (NSUB == 2)
+                asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst) : "s"(p));
+            else
+                asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(dst) : "s"(p));
         };
         issue(0, 0);
         load_queries();
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
                         __builtin_amdgcn_sched_barrier(0);  // (the wait stays behind the block's last MFMA)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(terms)::"memory");
                         scw[0] = __builtin_shufflevector(terms, terms, 0, 1, 2, 3);
-                        scw[1] = __builtin_shufflevector(terms, terms, 4, 5, 6, 7);
+                        if constexpr (NSUB == 2) scw[1] = __builtin_shufflevector(terms, terms, 4, 5, 6, 7);
                     }
                     // lane (j, kg) holds rows 16 rh + 4 kg + r (r = 0..3) of query q0 + 16 g + j, for g = 0..3
                     auto epilogue = [&]() __attribute__((always_inline)) {
@@ -1926,16 +1932,16 @@ static int launch_scan_qt(const MfmaArgs& a, int mode, int device, hipStream_t s
     return HRS_OK;
 }
 
-template <int KS>
+template <int KS, int QG, int TR>
 static int launch_scan16(MfmaArgs a, const char* qb16, const hrs_corpus* c, int device, hipStream_t st) {
     a.group = c->group_main;
-    const size_t lds = scan_lds_bytes(64 * KS * 32, true);
+    const size_t lds = scan_lds_bytes(TR * KS * 32, true);
     static hrs_per_device_once attr;
     if (attr.need(device)) {
-        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan16<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HRS_CHECK_HIP(hipFuncSetAttribute((const void*)k_mfma_scan16<KS, QG, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.done(device);
     }
-    hipLaunchKernelGGL((k_mfma_scan16<KS>), dim3(HRS_NUM_CU), dim3(512), lds, st, a, qb16);
+    hipLaunchKernelGGL((k_mfma_scan16<KS, QG, TR>), dim3(HRS_NUM_CU), dim3(512), lds, st, a, qb16);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;
 }
@@ -2041,7 +2047,11 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         // on the shallow int8 kernels: 64 queries per wave; batches of up to 256 split the rows of a tile as well
         const int qt = (i8 && KS <= 12 && !ctx->scan_qt1) ? (bpad >= 512 ? 2 : 3) : 1;
         // the main pass of the large int8 batches runs on the 16 x 16 x 64 MFMA shape (k_mfma_scan16)
-        const bool shape16 = i8 && qt == 2 && TR == 64 && KS % 2 == 0 && !ctx->scan_shape32;
+        // (64 queries per wave up to depth 384 at batches of 512 and more; 32 queries per wave at depth 512: 3 % faster
+        // there.  At depth 1024 -- instantiated below, reached with HRS_SCAN_SHAPE16_DEEP=1 -- the 32 x 32 x 32 kernel is
+        // 5 % faster: 3.58 against 3.77 ms over 4M rows at batch 1024, top-100.)
+        static const bool shape16_deep = getenv("HRS_SCAN_SHAPE16_DEEP") != nullptr;
+        const bool shape16 = i8 && !ctx->scan_shape32 && ((qt == 2 && TR == 64 && KS % 2 == 0) || (qt == 1 && (KS == 16 || (KS == 32 && shape16_deep))));
         const int nqg = bpad / (wide ? 128 : MF_QPB * (qt == 2 ? 2 : 1));
         const int nslices = HRS_NUM_CU / nqg;
         // cleared by the convert kernel: this chunk's deferred-queue length; for the first chunk also the
@@ -2150,7 +2160,9 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         HRS_SCAN_PROF_RESET                                                                          \
         hrs_prof_begin(ctx, st);                                                                     \
         if constexpr (I8_ && KS_ <= 12 && KS_ % 2 == 0 && TR_ == 64) {                               \
-            rc = shape16 ? launch_scan16<KS_>(a, (const char*)(ws + o_qb16), c, ctx->device, st) : scan(0); \
+            rc = shape16 ? launch_scan16<KS_, 4, 64>(a, (const char*)(ws + o_qb16), c, ctx->device, st) : scan(0); \
+        } else if constexpr (I8_ && (KS_ == 16 || KS_ == 32)) {                                      \
+            rc = shape16 ? launch_scan16<KS_, 2, TR_>(a, (const char*)(ws + o_qb16), c, ctx->device, st) : scan(0); \
         } else {                                                                                     \
             rc = scan(0);                                                                            \
         }                                                                                            \

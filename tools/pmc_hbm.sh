@@ -11,6 +11,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "== $c" >> $out
   rm -rf gpurun_out/pmc_$c
   timeout -s KILL 120 rocprofv3 --pmc $c -d gpurun_out/pmc_$c --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-extras --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
-  python3 tools/pmc_summary.py gpurun_out/pmc_$c "k_mfma_scan16<12>" >> $out
+  python3 tools/pmc_summary.py gpurun_out/pmc_$c "k_mfma_scan16<12, 4, 64>" >> $out
 done
 cat $out

@@ -13,10 +13,10 @@ import csv, glob, sys
 tag = sys.argv[1]
 f = sorted(glob.glob("gpurun_out/prof_bench/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-main = [r for r in rows if "k_mfma_scan16<12>" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 1_000_000]
+main = [r for r in rows if "k_mfma_scan16<12, 4, 64>" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 1_000_000]
 with open(f"gpurun_out/{tag}_main_kernel_launches.txt", "w") as o:
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in main]
-    o.write("k_mfma_scan16<12> (main pass, int8, v_mfma_i32_16x16x64_i8) launches over the 10M-row corpus, ms, in order:\n" + " ".join("%.3f" % x for x in d) + "\n")
+    o.write("k_mfma_scan16<12, 4, 64> (main pass, int8, v_mfma_i32_16x16x64_i8) launches over the 10M-row corpus, ms, in order:\n" + " ".join("%.3f" % x for x in d) + "\n")
     if len(d) >= 10:
         o.write("mean of the last ten (the timed steps): %.3f ms\n" % (sum(d[-10:]) / 10))
 P
