@@ -528,10 +528,15 @@ def main():
         used_mfma = args.mode == "mfma" or (args.mode == "auto" and n_local >= 65536 and (B > 4 or n_local * D >= cross))
         kern_avg_ms = kern_ms / max(launches, 1)
         if used_mfma:
-            flops = 2.0 * B * n_local * D  # algorithmic: 2*B*N*D per pass of this GPU's shard
+            # algorithmic: 2*B*N*D per pass of this GPU's shard -- times the share of the tiles that the timed kernel scores
+            # itself (the second sampled pass records the rows of its own tiles, about one in 64, and the main pass
+            # leaves those out: the library reports the share)
+            share = eng.scan_work()
+            flops = 2.0 * B * n_local * D * share
             achieved = flops / (kern_avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[shadow]
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "kernel": f"k_mfma_scan<main,{shadow}>", "kernel_ms": kern_avg_ms,
+                    "main_pass_share_of_tiles": share,
                     "peak_measured": MFMA_MEASURED_TFLOPS[shadow], "frac_of_measured": achieved / MFMA_MEASURED_TFLOPS[shadow],
                     "peak_measured_source": "LDS-fed MFMA loop on random operands (tools/micro/mfma_micro), profiles/r03_mfma_micro.txt"}
         else:

@@ -48,6 +48,7 @@ EXPORTS = [
     "hrs_postings_release_inverted",
     "hrs_match_counts",
     "hrs_score_topk_levels",
+    "hrs_scan_work",
     "hrs_classes_finish",
     "hrs_fuse_sort",
     "hrs_bm25_scores",
@@ -113,6 +114,7 @@ def lib():
             "hrs_postings_release_inverted": ([vp, vp], i32),
             "hrs_match_counts": ([vp, vp, vp, vp, i32, i64, vp, vp], i32),
             "hrs_score_topk_levels": ([vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp], i32),
+            "hrs_scan_work": ([vp, vp, vp], i32),
             "hrs_classes_finish": ([vp, vp, vp, i32, i32, i32, dbl, i32, vp, vp, vp, vp, vp], i32),
             "hrs_keyword_counts": ([vp, vp, vp, vp, vp, i32, i32, vp, vp], i32),
             "hrs_fuse_sort": ([vp, vp, vp, vp, i32, i32, dbl, i32, vp, vp, vp], i32),

@@ -404,6 +404,15 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     return HRS_OK;
 }
 
+extern "C" int hrs_scan_work(hrs_ctx* ctx, void* stream, double* main_pass_share) {
+    HRS_REQUIRE(ctx && main_pass_share, "hrs_scan_work: null argument");
+    HRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int64_t scored = 0;
+    HRS_CHECK_HIP(hipMemcpy(&scored, ctx->stats_dev + 8, sizeof(scored), hipMemcpyDeviceToHost));
+    *main_pass_share = (scored > 0 && ctx->last_tiles > 0) ? (double)scored / (double)ctx->last_tiles : 1.0;
+    return HRS_OK;
+}
+
 extern "C" int hrs_postings_register(hrs_ctx* ctx, const int64_t* doc_offs_dev, const int32_t* term_ids_dev,
                                      int64_t N, int64_t row_offset, hrs_postings** out) {
     HRS_REQUIRE(ctx && out && doc_offs_dev, "hrs_postings_register: null argument");

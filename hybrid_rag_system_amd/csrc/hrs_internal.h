@@ -62,7 +62,8 @@ struct hrs_ctx {
     hrs_workspace ws_mfma;     // MFMA scan: bf16 queries, maxima, tau, counters, candidate lists
     hrs_workspace ws_keys;     // result keys when the caller asks only for distances / rows
     std::vector<void*> retired;  // outgrown workspace blocks, freed when the context is destroyed (see hrs_ws_reserve)
-    int64_t* stats_dev = nullptr;  // [8] counters of the last MFMA call
+    int64_t* stats_dev = nullptr;  // [16] counters of the last MFMA call
+    int64_t last_tiles = 0;        // corpus tiles of the last MFMA call (see hrs_scan_work)
     // two contexts that serve alternate batches on two streams: each scan waits for the peer's last scan,
     // so scans never share the matrix pipes with each other, only with the peer's re-score tail
     hrs_ctx* peer = nullptr;

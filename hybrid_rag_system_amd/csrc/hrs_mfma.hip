@@ -111,6 +111,9 @@ struct MfmaArgs {
     float* tau_out;        // [Bpad] MODE 0: the threshold the pass filtered by (raised where the ladder says so)
     int raise_ss;          // MODE 0: sampling stride of the ladder pass
     int raise_limit;       // MODE 0: estimated rows above the threshold that a list may hold
+    long long* work;       // nullable: tiles scored by the main pass (k_mfma_scan16 adds; others leave it at 0 = all)
+    int ladder_records;    // the ladder pass records the rows above tau of its tiles, and the main pass (k_mfma_scan16,
+                           // which knows how to) leaves those tiles out: see ladder_tile
     int* cnt;              // [Bpad * MF_CNT_STRIDE], one counter per 128-byte line
     uint64_t* cand;        // [Bpad][HRS_CAND_CAP_BIG]
 #ifdef HRS_SCAN_PROF
@@ -147,6 +150,12 @@ __device__ __forceinline__ float raised_tau(const MfmaArgs& a, int q) {
     return t;
 }
 
+__device__ __forceinline__ uint32_t hash32(uint32_t x);
+// The tile that a sampled pass of stride ss takes from block n of a slice (blocks of ss consecutive tiles from t_begin).
+// The ladder pass and the main pass that leaves the ladder's tiles out must agree on it.
+__device__ __forceinline__ int64_t sampled_tile(int64_t t_begin, int slice, int64_t n, int ss) {
+    return t_begin + n * ss + (int64_t)(hash32((uint32_t)(slice * 0x9E3779B1u + n)) % (uint32_t)ss);
+}
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;
@@ -249,10 +258,13 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
     auto tile_at = [&](int64_t n) -> int64_t {
         if (n >= count) n = count - 1;
         if (!PRE) return t_begin + n;
-        int64_t t = t_begin + n * a.ss + (int64_t)(hash32((uint32_t)(slice * 0x9E3779B1u + n)) % (uint32_t)a.ss);
+        int64_t t = sampled_tile(t_begin, slice, n, a.ss);
         if (t >= full_tiles) t = full_tiles - 1;
         return t < 0 ? 0 : t;
     };
+    // ladder pass that records: a block whose tile had to be moved (the corpus' last, partial tile) records nothing --
+    // the main pass does not leave that block's tile out either
+    auto records_tile = [&](int64_t n) -> bool { return LADDER && a.ladder_records && n < count && sampled_tile(t_begin, slice, n, a.ss) < full_tiles; };
     // per-lane source offsets of this wave's DMA pieces (bytes from the tile base): piece p of row r
     // lands at LDS position p ^ (r & 15) of that row (the read side applies the same XOR)
     int srcoff[IPW];
@@ -371,6 +383,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (s / NB) * FSTEP);
         for (int64_t n = 0; n < count; ++n) {
             const int64_t tile = tile_at(n);
+            const bool rec = records_tile(n);
             f32xg terms;
             if constexpr (I8) terms_request(tile, terms);
             f32x4 scw[WSUB];  // the group terms of the 32-row groups this wave scores
@@ -480,11 +493,14 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                         if (MAXIMA) {
                             mx[qt][sb] = fmaxf(mx[qt][sb], ((float)m + xb) * scw[sb].x);  // .x = s_g
                         } else if (LADDER) {
-                            if (((float)m + xb) * scw[sb].x > tau[qt]) {
+                            // (wave-uniform test when the rows are also recorded: the slot allocator is a ballot)
+                            const bool some = ((float)m + xb) * scw[sb].x > tau[qt];
+                            if (rec ? __builtin_amdgcn_ballot_w64(some) != 0 : some) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
                                     const float v = ((float)acc[qt][r] + xb) * scw[sb].x;
                                     if (v > tau[qt]) atomicAdd(&a.hist[(q0 + qt * 32 + i) * 16 + max(0, min(15, (int)((v - tau[qt]) * linv[qt])))], 1);
+                                    if (rec) append(v > tau[qt], r, [&]() { return v; });
                                 }
                             }
                         } else {
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
         pt3 = wall_clock64();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (MODE == 0) flush_wave();  // what is still staged
+        if (MODE == 0 || (LADDER && a.ladder_records)) flush_wave();  // what is still staged
     } else {
         load_queries();  // (for the threshold that the first slice publishes)
     }
@@ -631,8 +647,60 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
 
     const int64_t t_begin = a.tiles * slice / nslices;
     const int64_t t_end = a.tiles * (slice + 1) / nslices;
-    const int64_t count = t_end - t_begin;
-    auto tile_at = [&](int64_t n) -> int64_t { return t_begin + (n >= count ? count - 1 : n); };
+    // Where the ladder pass has recorded the rows of its own tiles (a.ladder_records), those tiles are left out here:
+    // one per block of raise_ss tiles, at the position sampled_tile gives -- unless that position is the corpus' last,
+    // partial tile, which the ladder pass moved away from and did not record.  The tiles of this slice are walked by
+    // two cursors of the same kind, one for the DMA requests and one, a few tiles behind, for the tile being scored.
+    const int ss2 = a.raise_ss;
+    const int64_t full_tiles = a.N / TR;
+    const int64_t nblk = a.ladder_records ? (t_end - t_begin) / ss2 : 0;  // blocks the ladder pass took a tile from
+    struct Cursor {
+        int64_t next;     // the tile the next call returns (t_end: none left)
+        int64_t blk;      // its block
+        int64_t blk_end;  // first tile behind that block
+        int64_t skip;     // the tile left out of that block (-1: none)
+    };
+    auto skip_of = [&](int64_t blk) -> int64_t {
+        if (blk >= nblk) return -1;
+        const int64_t t = sampled_tile(t_begin, slice, blk, ss2);
+        return t < full_tiles ? t : -1;
+    };
+    auto cursor_settle = [&](Cursor& c) {  // moves `next` off a tile that is left out
+        while (c.next < t_end) {
+            if (c.next >= c.blk_end) {  // (no division here: this runs once per tile, on the scalar unit)
+                ++c.blk;
+                c.blk_end += ss2;
+                c.skip = skip_of(c.blk);
+            }
+            if (c.next != c.skip) break;
+            ++c.next;
+        }
+    };
+    auto cursor_init = [&](Cursor& c) {
+        c.next = t_begin;
+        c.blk = 0;
+        c.blk_end = t_begin + ss2;
+        c.skip = skip_of(0);
+        cursor_settle(c);
+    };
+    int64_t last_tile = t_begin;  // (what the request cursor returns once the slice is used up: requests stay uniform)
+    auto cursor_take = [&](Cursor& c) -> int64_t {
+        if (c.next >= t_end) return last_tile;
+        const int64_t t = c.next++;
+        cursor_settle(c);
+        return t;
+    };
+    // tiles of this slice that this pass scores: all but one per block -- only the block that holds the corpus' partial
+    // last tile may have kept all of its own
+    int64_t count = (t_end - t_begin) - nblk;
+    if (nblk && full_tiles >= t_begin && full_tiles < t_begin + nblk * ss2 && skip_of((full_tiles - t_begin) / ss2) < 0) ++count;
+    Cursor cur_dma, cur_run;
+    cursor_init(cur_dma);
+    cursor_init(cur_run);
+#ifndef HRS_SCAN_PROF
+    // (for hrs_scan_work: how many of the corpus' tiles this pass scores -- one workgroup per slice reports)
+    if (qg == 0 && threadIdx.x == 0 && a.work) atomicAdd((unsigned long long*)a.work, (unsigned long long)count);
+#endif
     int srcoff[IPW];
 #pragma unroll
     for (int ii = 0; ii < IPW; ++ii) {
@@ -641,8 +709,10 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
         srcoff[ii] = r * RB + ((p ^ (SWB == 4 ? (r & 15) : ((r >> 1) & 7))) << 4);
     }
     const uint32_t lds0 = lds_addr_of(smem);
-    auto issue = [&](int64_t n, int buf) {
-        const char* base = uniform_ptr(a.shadow + tile_at(n) * (int64_t)TILE_BYTES);
+    auto issue = [&](int64_t, int buf) {  // requests come in the order of the tiles: the cursor knows which is next
+        const int64_t t = cursor_take(cur_dma);
+        last_tile = t;
+        const char* base = uniform_ptr(a.shadow + t * (int64_t)TILE_BYTES);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * TILE_BYTES + wv * (IPW * 1024));
 #pragma unroll
         for (int ii = 0; ii < IPW; ++ii) glds16_asm(base, srcoff[ii], dst + ii * 1024);
@@ -729,7 +799,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan16(MfmaArgs a, const char* __r
             const uint64_t ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
             for (int64_t n = 0; n < count; ++n) {
-                const int64_t tile = tile_at(n);
+                const int64_t tile = cursor_take(cur_run);
                 f32xg terms;
                 terms_request(tile, terms);
                 f32x4 scw[NSUB];
@@ -2062,7 +2132,7 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         z.p[1] = qbase == 0 ? nflag : nullptr;
         z.n[1] = 64;
         z.p[2] = qbase == 0 ? (int32_t*)ctx->stats_dev : nullptr;
-        z.n[2] = 16;
+        z.n[2] = 18;  // (32-bit words: the nine 64-bit counters 0..8)
         if (!do_scan) {
         } else if (i8)
             hipLaunchKernelGGL(k_convert_q_i8, dim3((bpad + 3) / 4), dim3(256), 0, st, Q + (size_t)qbase * c->D, bc, c->D,
@@ -2107,6 +2177,15 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         a.mask = mask;
         a.lad_inv = (const float*)(ws + o_lad);
         a.hist = (int*)(ws + o_hist);
+        // the ladder pass records its tiles and the main pass leaves them out where the main pass is the kernel that can
+        // (HRS_LADDER_PLAIN: every main pass scores every tile, as the other kernels do)
+        static const bool ladder_plain = getenv("HRS_LADDER_PLAIN") != nullptr;
+        a.ladder_records = shape16 && !ladder_plain;
+        a.work = (long long*)ctx->stats_dev + 8;
+        if (do_scan) {  // (per chunk of queries, as the kernel's count; the tail half of a two-phase call leaves it alone)
+            if (qbase == 0) ctx->last_tiles = 0;
+            if (shape16) ctx->last_tiles += tiles;
+        }
         const int M = nslices * 2 * (TR / 32);
         // aim at ~max(384, per_k * k) rows above tau; the expected count is ss * M * -ln(1 - j/M).  The int8 shadow
         // ranks by an upper bound that sits a third of a sigma above the score at depth 384 and half a sigma at depth

@@ -277,6 +277,12 @@ class Engine:
         N.check(N.lib().hrs_score_stats(self._ctx, _stream(), out), "hrs_score_stats")
         return {"fallback_queries": out[0], "max_candidates": out[1], "overflow_queries": out[2]}
 
+    def scan_work(self):
+        """-> share of the corpus' tiles that the last matrix-core call's main pass scored itself (see hrs_scan_work)."""
+        share = C.c_double()
+        N.check(N.lib().hrs_scan_work(self._ctx, _stream(), C.byref(share)), "hrs_scan_work")
+        return share.value
+
     def profile(self, on=True):
         N.check(N.lib().hrs_profile_enable(self._ctx, int(on)), "hrs_profile_enable")
 

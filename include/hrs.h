@@ -174,6 +174,10 @@ int hrs_score_topk_static(hrs_ctx* ctx, hrs_corpus* corpus, const float* Q_dev, 
  * out[0] = queries that took the exact fallback, out[1] = largest candidate count of a query,
  * out[2] = queries whose candidate list overflowed. Waits for `stream`. */
 int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]);
+/* Measurement aid (no counterpart in the reference): the share of the corpus' tiles that the main pass of the last
+ * matrix-core call on this context scored itself -- 1.0, or a little less where the second sampled pass has recorded
+ * the rows of its own tiles and the main pass leaves those out.  Waits for the stream. */
+int hrs_scan_work(hrs_ctx* ctx, void* stream, double* main_pass_share);
 
 /* Kernel timing for benchmarks: while enabled, every launch of the dominant scan kernel (the MFMA
  * main pass in MFMA mode, the fp64 streaming scan in a direct EXACT-mode call) is bracketed by HIP

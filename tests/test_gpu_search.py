@@ -863,3 +863,25 @@ def test_bm25_keyword_scores_and_fusion(eng):
     assert np.array_equal(gp.cpu().numpy(), wp)
     assert np.array_equal(gc.cpu().numpy().view(np.uint64), wc.view(np.uint64))
     post.close()
+
+
+def test_main_pass_share_is_reported(eng):
+    """hrs_scan_work: the second sampled pass records the rows of its own tiles (one per block of its stride) and the
+    main pass of the large int8 batches leaves those tiles out; the library reports what share of the corpus' tiles
+    that main pass scored itself, and the keys are the oracle's all the same (a tile left out twice, or scored
+    twice, would show as a missing or a doubled key)."""
+    rng = np.random.default_rng(404)
+    n, d, b, k = 400_003, 128, 600, 20
+    C = _unit(rng, n, d)
+    Q = _unit(rng, b, d)
+    Q[:50] = C[rng.integers(0, n, 50)] + 0.05 * rng.standard_normal((50, d)).astype(np.float32)
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    _, _, keys = eng.score_topk(corpus, torch.from_numpy(Q).cuda(), k, mode="mfma", want_keys=True)
+    torch.cuda.synchronize()
+    share = eng.scan_work()
+    assert 0.9 < share < 1.0, share
+    want = so.topk_keys(Q, C, k, "l2")
+    assert np.array_equal(_keys(keys), want)
+    st = eng.score_stats()
+    assert st["fallback_queries"] <= 6, st
+    corpus.close()
