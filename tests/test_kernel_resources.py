@@ -19,11 +19,20 @@ def _flags(src):
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"] + (["-fno-slp-vectorize"] if src == "hrs_encoder.hip" else [])
 
 
+_ASM = {}  # source file -> its generated assembly (one compilation per file and test session)
+
+
+def _assembly(src, tmp_path):
+    if src not in _ASM:
+        out = tmp_path / (src + ".s")
+        subprocess.check_call([HIPCC] + _flags(src) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
+        _ASM[src] = out.read_text()
+    return _ASM[src]
+
+
 def _metadata(src, tmp_path):
-    out = tmp_path / (src + ".s")
-    subprocess.check_call([HIPCC] + _flags(src) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
     kernels, cur = {}, {}
-    for line in out.read_text().splitlines():
+    for line in _assembly(src, tmp_path).splitlines():
         m = re.match(r"\s+\.(name|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|vgpr_count):\s+(\S+)", line)
         if not m:
             if line.strip().startswith("- .") and cur.get("name"):
@@ -47,11 +56,8 @@ def test_asm_mfma_kernels_do_not_spill(src, needle, tmp_path):
 
 
 def _kernel_bodies(src, tmp_path):
-    out = tmp_path / (src + ".s")
-    if not out.exists():
-        subprocess.check_call([HIPCC] + _flags(src) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], stderr=subprocess.DEVNULL)
     bodies, name, cur = {}, None, []
-    for line in out.read_text().splitlines():
+    for line in _assembly(src, tmp_path).splitlines():
         m = re.match(r"^(_Z\w+):", line)
         if m:
             name, cur = m.group(1), []
