@@ -12,11 +12,11 @@ def run(eng, seed, cases, verbose=True, large=False):
   for it in range(cases):
       n = int(rng.choice([4096, 5000, 9999, 33000, 70001, 131072]))
       d = int(rng.choice([4, 8, 60, 64, 100, 128, 132, 256, 384, 388, 512, 516, 768, 1024])) 
-      b = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 257, 300]))
+      b = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 257, 300, 513, 700]))  # (from 513: the 16 x 16 x 64 main pass)
       if large:  # slices of many tiles: the sampled passes really sample (stride > 1)
           n = int(rng.choice([400_000, 1_000_003, 2_000_000]))
           d = int(rng.choice([64, 128, 384, 768, 1024]))
-          b = int(rng.choice([1, 4, 5, 33, 64, 130, 300, 600]))
+          b = int(rng.choice([1, 4, 5, 33, 64, 130, 300, 600, 600, 1024]))
           while n * d * b > 1.2e11: b = max(1, b // 2)
       k = int(rng.choice([1, 3, 10, 20, 64, 128]))
       if n < k * 64: k = 10
