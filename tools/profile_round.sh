@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 tag="$1"
 rm -rf gpurun_out/prof_bench gpurun_out/prof_enc
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_profiled_run.json 2> gpurun_out/${tag}_profiled_run.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${tag}_profiled_run.json 2> gpurun_out/${tag}_profiled_run.err
 cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | tail -1) gpurun_out/${tag}_kernel_stats.csv
 python3 - "$tag" <<'P'
 import csv, glob, sys
