@@ -133,13 +133,7 @@ def hybrid_query(query_text, n_results=5, collection_name=None, keyword_boost=0.
     the 2n nearest; with full_corpus the classes are still the reference's match counts."""
     collection = get_collection(collection_name)
     keywords = extract_keywords(query_text)
-    scoring = keyword_scoring or os.getenv("HRS_KEYWORD_SCORE") or "fraction"
-    if scoring not in ("fraction", "bm25"):
-        raise ValueError(f"keyword_scoring {scoring!r}: 'fraction' or 'bm25'")
-    keyword_score = calculate_keyword_score
-    if scoring == "bm25" and keywords:
-        df, n_docs, avg_len = collection.keyword_stats(keywords)
-        keyword_score = lambda doc, kws: bm25_keyword_score(doc, kws, df, n_docs, avg_len)
+    keyword_score = _keyword_score_fn(collection, keywords, keyword_scoring)
     if full_corpus is None:
         full_corpus = os.getenv("HRS_HYBRID_FULL") == "1"
     if full_corpus and keywords:
@@ -176,13 +170,27 @@ def query_batch(query_texts, n_results=5, collection_name=None, where_filter=Non
     return collection.query(**params)
 
 
-def hybrid_query_batch(query_texts, n_results=5, collection_name=None, keyword_boost=0.3):
+def _keyword_score_fn(collection, keywords, keyword_scoring):
+    """The candidates' keyword score: the reference's fraction, or (an extension) BM25 over the collection's statistics."""
+    scoring = keyword_scoring or os.getenv("HRS_KEYWORD_SCORE") or "fraction"
+    if scoring not in ("fraction", "bm25"):
+        raise ValueError(f"keyword_scoring {scoring!r}: 'fraction' or 'bm25'")
+    if scoring == "bm25" and keywords:
+        df, n_docs, avg_len = collection.keyword_stats(keywords)
+        return lambda doc, kws: bm25_keyword_score(doc, kws, df, n_docs, avg_len)
+    return calculate_keyword_score
+
+
+def hybrid_query_batch(query_texts, n_results=5, collection_name=None, keyword_boost=0.3, keyword_scoring=None):
     query_texts = list(query_texts)
     res = query_batch(query_texts, n_results * 2, collection_name)
-    return [
-        _fuse(res["documents"][b], res["metadatas"][b], res["ids"][b], res["distances"][b], extract_keywords(q), n_results, keyword_boost)
-        for b, q in enumerate(query_texts)
-    ]
+    collection = get_collection(collection_name)
+    out = []
+    for b, q in enumerate(query_texts):
+        kws = extract_keywords(q)
+        out.append(_fuse(res["documents"][b], res["metadatas"][b], res["ids"][b], res["distances"][b], kws, n_results, keyword_boost,
+                         _keyword_score_fn(collection, kws, keyword_scoring)))
+    return out
 
 
 # ---- add / index -----------------------------------------------------------------------------------

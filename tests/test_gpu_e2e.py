@@ -266,5 +266,7 @@ def test_bm25_keyword_scoring_on_the_text_path(helper, monkeypatch):
         monkeypatch.delenv("HRS_KEYWORD_SCORE")
         assert helper.hybrid_query(q, 5, "cfg1") == plain
     assert changed >= 1
+    qs = QUERIES[:3]
+    assert helper.hybrid_query_batch(qs, 5, "cfg1", keyword_scoring="bm25") == [helper.hybrid_query(q, 5, "cfg1", keyword_scoring="bm25") for q in qs]
     with pytest.raises(ValueError):
         helper.hybrid_query("x y z", 5, "cfg1", keyword_scoring="tfidf")
