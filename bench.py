@@ -201,6 +201,59 @@ def bench_scan(eng, corpus, queries, k=10):
     return out
 
 
+def bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep, k1=1.2, b=0.75):
+    """The headline's hybrid step with BM25 weights in the place of the keyword fraction (an extension: the reference
+    scores the fraction of keywords present): top-2n by distance, BM25 of the candidates from their term lists (term
+    frequency, list length, idf from the document frequencies of the inverted postings), fusion, first n.  Checked on
+    sampled queries against the same arithmetic in Python floats, bit for bit (the run aborts otherwise)."""
+    from hybrid_rag_system_amd.engine import Postings
+
+    n = corpus.n
+    B = queries.shape[0]
+    df = (inv.term_offs[1:] - inv.term_offs[:-1]).to(torch.float64)
+    idf = torch.log(1.0 + (float(n) - df + 0.5) / (df + 0.5)).contiguous()
+    doc_offs = torch.arange(n + 1, dtype=torch.int64, device=eng.device) * TERMS_PER_DOC
+    postings = Postings(eng, doc_offs, terms.reshape(-1), 0)
+    par = {"idf": idf, "avg_len": float(TERMS_PER_DOC), "k1": k1, "b": b}
+    run = lambda: eng.hybrid_topk(corpus, postings, queries, q_terms, q_offs, n_keep, bm25=par)
+    out = run()
+    torch.cuda.synchronize()
+    idf_h, qt_h, qo_h = idf.cpu().numpy(), q_terms.cpu().numpy(), q_offs.cpu().numpy()
+    for q in (0, B // 2, B - 1):
+        rows, dist = out["cand_rows"][q].cpu().numpy(), out["cand_dist"][q].cpu().numpy()
+        kw_gpu = out["cand_kw"][q].cpu().numpy()
+        mine = [int(t) for t in qt_h[qo_h[q] : qo_h[q + 1]]]
+        scored = []
+        for j, r in enumerate(rows):
+            lst = terms[int(r)].cpu().numpy().tolist()
+            norm = k1 * ((1.0 - b) + b * (float(len(lst)) / float(TERMS_PER_DOC)))
+            score = best = 0.0
+            for t in mine:
+                w = float(idf_h[t])
+                best = best + w * (k1 + 1.0)
+                f = lst.count(t)
+                if f > 0:
+                    score = score + ((w * float(f)) * (k1 + 1.0)) / (float(f) + norm)
+            kw = score / best if best > 0.0 else 0.0
+            if np.float64(kw).view(np.uint64) != kw_gpu[j : j + 1].view(np.uint64)[0]:
+                raise SystemExit(f"BM25 hybrid step: keyword weight of query {q}, candidate {j} differs from the host recount")
+            scored.append((max(0.0, 1.0 - float(dist[j])) * (1.0 - 0.3) + kw * 0.3, j))
+        scored.sort(key=lambda x: x[0], reverse=True)
+        want = [j for _, j in scored[:n_keep]]
+        if out["perm"][q].cpu().numpy().tolist() != want:
+            raise SystemExit(f"BM25 hybrid step: fused order of query {q} differs from the host's")
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    postings.close()
+    return {"queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
+            "config": f"sequential calls: top-{2 * n_keep} by distance over {n} x {corpus.dim}, BM25 (k1 {k1}, b {b}) of the candidates over their term lists, fusion -> top-{n_keep}",
+            "checked": "3 queries: BM25 weights and fused order equal Python-float arithmetic bit for bit"}
+
+
 def bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep, B=64):
     """The full-corpus hybrid mode (an extension: the fused score over EVERY row, not over the 2n nearest) at the
     headline's size: match counts of all rows from inverted postings, the nearest n of every match-count class -- all
@@ -233,9 +286,10 @@ def bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep, B=64
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     levels = int((qo[1:] - qo[:-1]).max().item()) + 1
+    bm25 = bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep)
     inv.close()
     passes = (B + 3) // 4
-    return {"queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "classes": levels, "corpus_passes": passes,
+    return {"bm25_hybrid_step": bm25, "queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "classes": levels, "corpus_passes": passes,
             "algorithmic_GBps": passes * n * corpus.dim * 4 / dt / 1e9, "hbm_frac": passes * n * corpus.dim * 4 / dt / 1e9 / HBM_PEAK_GBPS,
             "inverted_index_build_s": build_s,
             "config": f"{n} x {corpus.dim} fp32 corpus, {B} queries of 1-8 keywords, top-{n_keep} of the whole corpus under the fused score; the time includes the match counts of every row and the fusion",
