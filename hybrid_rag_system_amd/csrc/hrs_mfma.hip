@@ -1599,7 +1599,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
         }
     };
     // first round: the rows that must be re-scored for a proof are those whose recorded bound reaches the k-th best
-    // exact score -- for the int8 shadow several times k, rarely more than 8 k + 48 (the launcher's first_rows)
+    // exact score -- for the int8 shadow several times k, rarely more than 8 k + 32 (the launcher's first_rows)
     int first = a.first_rows;
     // The first round needs the `first` best candidates by recorded score as a SET, in no order, and nearly every
     // query is settled by it: instead of sorting the list, the small variant bins the recorded scores (1024 bins over
@@ -1777,6 +1777,8 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
             const int lane = tid & 63;
             const int idx = done + tid;
             const bool live = idx < want;
+            // (a wave none of whose 64 candidates exists has nothing to fetch or to add up: its staging block is its own)
+            const bool wave_live = __builtin_amdgcn_readfirstlane(done + (tid & ~63)) < want;
             const uint32_t grow = live ? (uint32_t)(s[idx] & 0xFFFFFFFFull) : 0u;
             // (a thread without a candidate still helps to fetch: it points at the first row)
             const float* cr = live ? a.C + (size_t)((int64_t)grow - a.row_offset) * a.D : a.C;
@@ -1784,6 +1786,8 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
             // (typed as global memory: a pointer rebuilt from integers would otherwise be loaded from with flat
             // instructions, which count as LDS operations too and would make every LDS wait a memory wait)
             typedef const __attribute__((address_space(1))) char* gptr;
+            double acc = 0.0, nc = 0.0;
+            if (wave_live) {
             gptr fp[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1795,7 +1799,6 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
             char* wl = stage + (tid >> 6) * (64 * 144);
             char* wr_base = wl + (lane >> 3) * 144 + (lane & 7) * 16;
             const char* rd_base = wl + lane * 144;
-            double acc = 0.0, nc = 0.0;
             auto step4 = [&](const f32x4 cv, const float4 qv) __attribute__((always_inline)) {
                 const double c0 = cv.x, c1 = cv.y, c2 = cv.z, c3 = cv.w;
                 const double q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
@@ -1853,6 +1856,7 @@ __device__ __forceinline__ void select_rescore_one(const SelectArgs& a, int ql) 
                     }
                 }
             }
+            }  // waves with candidates
             if (live) {
                 double d;
                 if (SPACE == HRS_SPACE_L2)
@@ -2322,7 +2326,8 @@ int hrs_launch_mfma(hrs_ctx* ctx, hrs_corpus* c, const float* Q, int B, int k, i
         s.qbase = qbase;
         {
             static const int first_env = getenv("HRS_SEL_FIRST") ? atoi(getenv("HRS_SEL_FIRST")) : 0;
-            int first = first_env > 0 ? first_env : ((8 * k + 48 + 63) & ~63);
+            // (whole waves of 64: a wave without candidates skips the round)
+            int first = first_env > 0 ? first_env : ((8 * k + 32 + 63) & ~63);
             s.first_rows = first > HRS_RESCORE ? HRS_RESCORE : first;
         }
         // a proof needs about a quarter of the target re-scored (the rows whose bound reaches the k-th exact score); for
