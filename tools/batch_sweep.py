@@ -29,4 +29,15 @@ for B in (1, 2, 4, 8, 32, 128, 256, 512, 1024):
         moved = (N * D * 4 * passes if mode == "exact" else N * D) / (ms * 1e-3) / 1e9
         tf = 2.0 * B * N * D / (ms * 1e-3) / 1e12
         peak = 5000.0 if mode == "mfma" else 78.6
-        print(f"{B:5d}  {mode:5s}  {ms:8.3f}  {B/(ms*1e-3):10.0f}   {alg:8.0f}   {moved:8.0f} ({moved/8000:.2f})   {tf:8.1f} ({tf/peak:.2f})", flush=True)
+        main = ""
+        if mode == "mfma":
+            # the main pass alone (device events around the kernel): what it reaches of the HBM peak and of the rate an
+            # LDS-fed int8 MFMA loop holds on this chip (3050 TOP/s) -- whichever is nearer to 1 bounds it
+            eng.profile(True)
+            for _ in range(3): eng.score_topk(c, q, K, mode=mode)
+            torch.cuda.synchronize()
+            pms, pn = eng.profile_read()
+            eng.profile(False)
+            mp = pms / pn
+            main = f"   main pass {mp:.3f} ms: {N * D / (mp * 1e-3) / 1e9 / 8000:.2f} of HBM, {2.0 * B * N * D / (mp * 1e-3) / 1e12 / 3050:.2f} of the measured MFMA rate"
+        print(f"{B:5d}  {mode:5s}  {ms:8.3f}  {B/(ms*1e-3):10.0f}   {alg:8.0f}   {moved:8.0f} ({moved/8000:.2f})   {tf:8.1f} ({tf/peak:.2f}){main}", flush=True)
