@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) void k_mfma_scan(MfmaArgs a) {
                 // Main pass: the two waves of a SIMD would leave every barrier in step -- both in their MFMAs, then both
                 // in the vector work on their results, the matrix pipe idle.  Waves 0..3 look at the last group's results
                 // in front of the barrier, waves 4..7 behind it, which sets the partners half a phase apart.
-                const bool early = MODE == 0 && !RS && sb + 1 == WSUB && n + 1 < count && (!PAIR || (n & 1)) && wv < 4;
+                const bool early = MODE == 0 && sb + 1 == WSUB && n + 1 < count && (!PAIR || (n & 1)) && wv < 4;
                 if (sb + 1 < WSUB) {
 #pragma unroll
                     for (int s = 0; s < PF; ++s) pre[s] = *(lds_frag)(tb[s & (NB - 1)] + (sb + 1) * 32 * RB + (s / NB) * FSTEP);
