@@ -54,6 +54,7 @@ EXPORTS = [
     "hrs_bm25_scores",
     "hrs_fuse_sort_scores",
     "hrs_merge_topk",
+    "hrs_merge_topk_i64",
     "hrs_unpack_keys",
     "hrs_synth_rows",
     "hrs_synth_postings",
@@ -121,6 +122,7 @@ def lib():
             "hrs_bm25_scores": ([vp, vp, vp, i64, dbl, dbl, dbl, vp, vp, vp, i32, i32, vp, vp], i32),
             "hrs_fuse_sort_scores": ([vp, vp, vp, i32, i32, dbl, i32, vp, vp, vp], i32),
             "hrs_merge_topk": ([vp, vp, vp, i32, i32, i32, vp, vp, vp], i32),
+            "hrs_merge_topk_i64": ([vp, vp, vp, i32, i32, i32, vp, vp, vp], i32),
             "hrs_unpack_keys": ([vp, vp, i64, vp, vp, vp], i32),
             "hrs_synth_rows": ([vp, u64, i64, i64, i32, i32, vp, vp], i32),
             "hrs_synth_postings": ([vp, u64, i64, i64, i32, i32, vp, vp, vp], i32),

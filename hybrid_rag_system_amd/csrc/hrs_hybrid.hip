@@ -273,12 +273,14 @@ extern "C" int hrs_classes_finish(hrs_ctx* ctx, const uint64_t* keys_dev, const 
 }
 
 // Cross-shard merge: keys are globally unique (the row is part of the key), so the payload of each
-// output key is found again by position after sorting (key, source slot) pairs.
-__global__ __launch_bounds__(256) void k_merge_topk(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+// output key is found again by position after sorting (key, source slot) pairs.  VT: the payload's type (int32 keyword
+// counts, or 64 bits that are moved and never looked at: BM25 keyword scores).
+template <typename VT>
+__global__ __launch_bounds__(256) void k_merge_topk(const uint64_t* __restrict__ keys, const VT* __restrict__ vals,
                                                     int G, int B, int k, uint64_t* __restrict__ out_keys,
-                                                    int32_t* __restrict__ out_vals) {
+                                                    VT* __restrict__ out_vals) {
     __shared__ uint64_t s[2048];
-    __shared__ int32_t v[2048];
+    __shared__ VT v[2048];
     const int b = blockIdx.x;
     const int n = G * k;
     int n2 = 1;
@@ -331,7 +333,20 @@ extern "C" int hrs_merge_topk(hrs_ctx* ctx, const uint64_t* keys_dev, const int3
     HRS_REQUIRE(!(out_vals_dev && !vals_dev), "hrs_merge_topk: out_vals without vals");
     if (B <= 0) return HRS_OK;
     HRS_CHECK_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_merge_topk, dim3(B), dim3(256), 0, (hipStream_t)stream, keys_dev, vals_dev, G, B, k,
+    hipLaunchKernelGGL(k_merge_topk<int32_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, keys_dev, vals_dev, G, B, k,
+                       out_keys_dev, out_vals_dev);
+    HRS_CHECK_HIP(hipGetLastError());
+    return HRS_OK;
+}
+
+extern "C" int hrs_merge_topk_i64(hrs_ctx* ctx, const uint64_t* keys_dev, const int64_t* vals_dev, int G, int B, int k,
+                                  uint64_t* out_keys_dev, int64_t* out_vals_dev, void* stream) {
+    HRS_REQUIRE(ctx && keys_dev && vals_dev && out_keys_dev && out_vals_dev, "hrs_merge_topk_i64: null argument");
+    HRS_REQUIRE(G >= 1 && k >= 1 && (int64_t)G * k <= 2048, "hrs_merge_topk_i64: G*k=%lld outside [1, 2048]",
+                (long long)G * k);
+    if (B <= 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_merge_topk<int64_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, keys_dev, vals_dev, G, B, k,
                        out_keys_dev, out_vals_dev);
     HRS_CHECK_HIP(hipGetLastError());
     return HRS_OK;

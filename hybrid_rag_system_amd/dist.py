@@ -17,12 +17,14 @@ def shard_bounds(n_rows, world, rank):
 
 
 def pack_candidates(keys, counts):
-    """keys int64 [B,c] (uint64 bits) + counts int32 [B,c] -> int64 [B,c,2]."""
-    return torch.stack((keys, counts.to(torch.int64)), dim=-1).contiguous()
+    """keys int64 [B,c] (uint64 bits) + counts [B,c] (int32 keyword counts, or float64 keyword scores, which travel as
+    their bits) -> int64 [B,c,2]."""
+    second = counts.view(torch.int64) if counts.dtype == torch.float64 else counts.to(torch.int64)
+    return torch.stack((keys, second), dim=-1).contiguous()
 
 
 def allgather_candidates(keys, counts, group=None):
-    """All-gather every rank's (keys, counts) -> keys int64 [G,B,c], counts int32 [G,B,c]."""
+    """All-gather every rank's (keys, counts) -> keys int64 [G,B,c], counts [G,B,c] (int32, or float64 as given)."""
     world = dist.get_world_size(group)
     payload = pack_candidates(keys, counts)
     # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [G, B, c, 2]
@@ -36,7 +38,8 @@ def allgather_candidates(keys, counts, group=None):
         flat = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
         dist.all_gather_into_tensor(flat, payload, group=group)
     out = flat.view((world,) + tuple(payload.shape))
-    return out[..., 0].contiguous(), out[..., 1].to(torch.int32).contiguous()
+    second = out[..., 1].contiguous()
+    return out[..., 0].contiguous(), (second.view(torch.float64) if counts.dtype == torch.float64 else second.to(torch.int32))
 
 
 def exchange_classes(engine, group=None):
@@ -108,22 +111,29 @@ class ShardedHybrid:
     def exchanges(self):
         return self.group is not False and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def step(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
-        self.begin(queries, q_terms, q_term_offs, n, boost, space, mode)
+    def step(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto", bm25=None):
+        self.begin(queries, q_terms, q_term_offs, n, boost, space, mode, bm25)
         return self.finish()
 
-    def begin(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto"):
-        """The scan of a step (hrs_score_topk_begin); `finish` on the same stream does the rest."""
+    def begin(self, queries, q_terms, q_term_offs, n, boost=0.3, space="l2", mode="auto", bm25=None):
+        """The scan of a step (hrs_score_topk_begin); `finish` on the same stream does the rest.
+        bm25 = dict(idf=fp64 [V], avg_len=float[, k1, b]) as in Engine.hybrid_topk, with the statistics of the WHOLE
+        corpus (document frequencies and lengths summed over the shards when the collection was built): every shard
+        then weighs its own candidates exactly as an unsharded engine would, and the scores ride along in the
+        all-gather where the counts do otherwise (same payload size)."""
         # local top-2n of this shard is a superset of the shard's members of the global top-2n
         self.engine.score_topk_begin(self.corpus, queries, 2 * n, space=space, mode=mode)
-        self._open = (q_terms, q_term_offs, n, boost)
+        self._open = (q_terms, q_term_offs, n, boost, bm25)
 
     def finish(self):
         e = self.engine
-        q_terms, q_term_offs, n, boost = self._open
+        q_terms, q_term_offs, n, boost, bm25 = self._open
         self._open = None
         cand_dist, rows, keys = e.score_topk_finish(want_keys=True)
-        counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
+        if bm25 is not None:
+            counts = e.bm25_scores(self.postings, bm25["idf"], bm25["avg_len"], q_terms, q_term_offs, rows, bm25.get("k1", 1.2), bm25.get("b", 0.75))
+        else:
+            counts = e.keyword_counts(self.postings, q_terms, q_term_offs, rows)
         local = (cand_dist, rows)  # the candidates unpacked, as the scoring call wrote them
         cuda = _is_cuda(e)
         xs = self.exchange_stream if (cuda and self.exchanges()) else None
@@ -153,6 +163,9 @@ class ShardedHybrid:
             cand_dist, cand_rows = e.unpack_keys(keys)
         else:
             cand_dist, cand_rows = local
+        if counts.dtype == torch.float64:  # BM25 keyword scores
+            combined, perm = e.fuse_sort_scores(cand_dist, counts, n, boost)
+            return {"cand_dist": cand_dist, "cand_rows": cand_rows, "cand_kw": counts, "combined": combined, "perm": perm}
         combined, perm = e.fuse_sort(cand_dist, counts, q_term_offs, n, boost)
         return {"cand_dist": cand_dist, "cand_rows": cand_rows, "cand_counts": counts, "combined": combined, "perm": perm}
 

@@ -413,9 +413,14 @@ class Engine:
         return {k: torch.cat(v) for k, v in out.items()}
 
     def merge_topk(self, keys, vals=None):
-        """keys int64(uint64 bits) [G,B,k] (+ vals int32 [G,B,k]) -> best k per query."""
+        """keys int64(uint64 bits) [G,B,k] (+ vals [G,B,k]: int32, or 64-bit values -- int64 / float64 -- that are moved
+        as they are) -> best k per query."""
         G, B, k = keys.shape
         out = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        if vals is not None and vals.dtype in (torch.int64, torch.float64):
+            ov = torch.empty((B, k), dtype=vals.dtype, device=self.device)
+            N.check(N.lib().hrs_merge_topk_i64(self._ctx, _ptr(keys), _ptr(vals.contiguous()), G, B, k, _ptr(out), _ptr(ov), _stream()), "hrs_merge_topk_i64")
+            return out, ov
         ov = torch.empty((B, k), dtype=torch.int32, device=self.device) if vals is not None else None
         N.check(N.lib().hrs_merge_topk(self._ctx, _ptr(keys), _ptr(vals), G, B, k, _ptr(out), _ptr(ov), _stream()), "hrs_merge_topk")
         return (out, ov) if vals is not None else out

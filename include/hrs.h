@@ -290,6 +290,10 @@ int hrs_classes_finish(hrs_ctx* ctx, const uint64_t* keys_dev, const int32_t* q_
  * Writes the best k of each query's G*k keys (and their vals).  G * k <= 2048. */
 int hrs_merge_topk(hrs_ctx* ctx, const uint64_t* keys_dev, const int32_t* vals_dev, int G, int B, int k,
                    uint64_t* out_keys_dev, int32_t* out_vals_dev, void* stream);
+/* The same merge with a 64-bit payload per candidate, moved and never interpreted (the bits of the fp64 keyword scores
+ * of hrs_bm25_scores on a row-sharded corpus; slots without a key get 0). */
+int hrs_merge_topk_i64(hrs_ctx* ctx, const uint64_t* keys_dev, const int64_t* vals_dev, int G, int B, int k,
+                       uint64_t* out_keys_dev, int64_t* out_vals_dev, void* stream);
 /* keys -> (fp32 distance, int64 row); either output nullable. */
 int hrs_unpack_keys(hrs_ctx* ctx, const uint64_t* keys_dev, int64_t n, float* dist_dev, int64_t* rows_dev,
                     void* stream);

@@ -865,6 +865,66 @@ def test_bm25_keyword_scores_and_fusion(eng):
     post.close()
 
 
+def test_sharded_bm25_step_equals_unsharded(eng):
+    """BM25 weights on a row-sharded corpus: every shard scores its own top-2n with the statistics of the whole corpus,
+    the fp64 scores pass through hrs_merge_topk_i64 beside their keys as 64 opaque bits, and the fused result equals
+    the unsharded Engine.hybrid_topk(bm25=...) and the oracle, bit for bit (2, 3 and 8 shards)."""
+    rng = np.random.default_rng(912)
+    n, d, b, keep, V = 20_003, 96, 33, 6, 300
+    C = _unit(rng, n, d)
+    p = 1.0 / np.arange(1, V + 1)
+    p /= p.sum()
+    lens = rng.integers(1, 40, n)
+    lists = [rng.choice(V, int(l), replace=True, p=p).astype(np.int32) for l in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    terms = np.concatenate(lists).astype(np.int32)
+    df = np.zeros(V, np.int64)
+    for l in lists:
+        df[np.unique(l)] += 1
+    idf = so.bm25_idf(df, n)
+    avg_len = float(lens.mean())
+    m = rng.integers(0, 6, b)
+    qoffs = np.concatenate([[0], np.cumsum(m)]).astype(np.int32)
+    qterms = rng.choice(V, int(m.sum()), replace=True, p=p).astype(np.int32)
+    Q = _unit(rng, b, d)
+    dq, dqt, dqo = torch.from_numpy(Q).cuda(), torch.from_numpy(qterms).cuda(), torch.from_numpy(qoffs).cuda()
+    bm25 = {"idf": torch.from_numpy(idf).cuda(), "avg_len": avg_len}
+    # the oracle's answer
+    wd, wr = so.unpack(so.topk_keys(Q, C, 2 * keep, "l2"))
+    wkw = so.bm25_scores(offs, terms, idf, avg_len, qoffs, qterms, wr)
+    wc, wp = so.fuse_sort_scores(wd, wkw, keep, 0.3)
+    assert (wkw > 0).any()
+    corpus = eng.corpus(torch.from_numpy(C).cuda())
+    post = eng.postings(torch.from_numpy(offs).cuda(), torch.from_numpy(terms).cuda())
+    one = eng.hybrid_topk(corpus, post, dq, dqt, dqo, keep, bm25=bm25)
+    torch.cuda.synchronize()
+    assert np.array_equal(one["cand_rows"].cpu().numpy(), wr) and np.array_equal(one["perm"].cpu().numpy(), wp)
+    assert np.array_equal(one["combined"].cpu().numpy().view(np.uint64), wc.view(np.uint64))
+    corpus.close()
+    post.close()
+    for G in (2, 3, 8):
+        bounds = [n * g // G for g in range(G + 1)]
+        keys, kws, held = [], [], []
+        for g in range(G):
+            lo, hi = bounds[g], bounds[g + 1]
+            cp = eng.corpus(torch.from_numpy(C[lo:hi]).cuda(), row_offset=lo)
+            ps = eng.postings(torch.from_numpy(offs[lo : hi + 1] - offs[lo]).cuda(), torch.from_numpy(terms[offs[lo] : offs[hi]]).cuda(), row_offset=lo)
+            held += [cp, ps]
+            _, rows, k64 = eng.score_topk(cp, dq, 2 * keep, want_keys=True)
+            keys.append(k64)
+            kws.append(eng.bm25_scores(ps, bm25["idf"], avg_len, dqt, dqo, rows))
+        mk, mkw = eng.merge_topk(torch.stack(keys), torch.stack(kws))
+        md, mr = eng.unpack_keys(mk)
+        gc, gp = eng.fuse_sort_scores(md, mkw, keep, 0.3)
+        torch.cuda.synchronize()
+        assert mkw.dtype == torch.float64
+        assert np.array_equal(mr.cpu().numpy(), wr), G
+        assert np.array_equal(mkw.cpu().numpy().view(np.uint64), wkw.view(np.uint64)), G
+        assert np.array_equal(gp.cpu().numpy(), wp) and np.array_equal(gc.cpu().numpy().view(np.uint64), wc.view(np.uint64)), G
+        for h in held:
+            h.close()
+
+
 def test_main_pass_share_is_reported(eng):
     """hrs_scan_work: the second sampled pass records the rows of its own tiles (one per block of its stride) and the
     main pass of the large int8 batches leaves those tiles out; the library reports what share of the corpus' tiles
