@@ -87,6 +87,30 @@ def gather_rows(local_rows, n_total, group=None):
     return out.to(local_rows.device) if staged else out
 
 
+def bm25_corpus_stats(local_doc_freq, local_total_len, local_rows, group=None, device=None):
+    """The BM25 statistics of a row-sharded corpus, identical on every rank: one all-reduce (sum) of the shard's
+    document frequencies int64 [V], its summed document lengths and its row count, then
+    idf = ln(1 + (N - df + 0.5) / (df + 0.5)) in numpy float64 on the host (integers in, the same libm on every rank).
+    -> dict(idf=fp64 [V] on `device`, avg_len=float): the `bm25` argument of ShardedHybrid.step / Engine.hybrid_topk."""
+    import numpy as np
+
+    df = torch.as_tensor(local_doc_freq, dtype=torch.int64).cpu().reshape(-1)
+    packed = torch.cat((df, torch.tensor([int(local_total_len), int(local_rows)], dtype=torch.int64)))
+    if dist.is_initialized() and group is not False and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "gloo":
+            dist.all_reduce(packed, group=group)
+        else:  # RCCL reduces device tensors
+            dev = packed.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(dev, group=group)
+            packed = dev.cpu()
+    tot = packed.numpy()
+    n_rows, total_len = int(tot[-1]), int(tot[-2])
+    dfa = tot[:-2].astype(np.float64)
+    idf = np.log(1.0 + (float(n_rows) - dfa + 0.5) / (dfa + 0.5))
+    out = torch.from_numpy(idf)
+    return {"idf": out.to(device) if device is not None else out, "avg_len": float(total_len) / float(max(n_rows, 1))}
+
+
 def _is_cuda(engine):
     return getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
 

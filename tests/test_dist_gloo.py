@@ -188,18 +188,23 @@ def _bm25_stats(terms, V):
 
 
 def _bm25_worker(rank, world, port, ret):
-    from hybrid_rag_system_amd.dist import ShardedHybrid
+    from hybrid_rag_system_amd.dist import ShardedHybrid, bm25_corpus_stats
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     C, terms, offs, batches, qoffs, qterms = _hybrid_inputs()
-    idf, avg_len = _bm25_stats(terms, 60)
     lo, hi = shard_bounds(C.shape[0], world, rank)
+    # the statistics of the whole corpus from the shards' own: one all-reduce
+    df_local = np.zeros(60, np.int64)
+    for row in terms[lo:hi]:
+        df_local[np.unique(row)] += 1
+    stats = bm25_corpus_stats(df_local, terms[lo:hi].size, hi - lo)
+    idf, avg_len = _bm25_stats(terms, 60)
+    assert np.array_equal(stats["idf"].numpy().view(np.uint64), idf.view(np.uint64)) and stats["avg_len"] == avg_len
     postings = (offs[: hi - lo + 1].copy(), terms[lo:hi].reshape(-1), lo)
     searcher = ShardedHybrid(_OracleEngine(), (C[lo:hi], lo), postings)
-    out = searcher.step(torch.from_numpy(batches[0]), torch.from_numpy(qterms), torch.from_numpy(qoffs), 4, boost=0.4,
-                        bm25={"idf": torch.from_numpy(idf), "avg_len": avg_len, "k1": 1.5})
+    out = searcher.step(torch.from_numpy(batches[0]), torch.from_numpy(qterms), torch.from_numpy(qoffs), 4, boost=0.4, bm25=dict(stats, k1=1.5))
     assert searcher.bytes_gathered == 7 * 8 * 16  # the scores travel where the counts do: the same payload
     ret[rank] = {k: v.numpy() for k, v in out.items()}
     dist.destroy_process_group()
