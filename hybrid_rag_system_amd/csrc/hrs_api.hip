@@ -275,6 +275,7 @@ extern "C" int hrs_unpack_keys(hrs_ctx* ctx, const uint64_t* keys_dev, int64_t n
                                void* stream) {
     HRS_REQUIRE(ctx && keys_dev && n >= 0, "hrs_unpack_keys: bad arguments");
     if (n == 0) return HRS_OK;
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys_dev, n,
                        dist_dev, rows_dev);
     HRS_CHECK_HIP(hipGetLastError());
