@@ -252,6 +252,7 @@ extern "C" int hrs_corpus_shadow(hrs_ctx* ctx, hrs_corpus* c, int kind, void* st
 
 extern "C" int hrs_corpus_stats(hrs_ctx* ctx, hrs_corpus* c, void* stream, double* mn, double* mx) {
     HRS_REQUIRE(ctx && c, "hrs_corpus_stats: null handle");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
     double h[2] = {0, 0};
     if (c->N > 0) {
         HRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -378,6 +379,7 @@ extern "C" int hrs_score_topk_finish(hrs_ctx* ctx, uint64_t* keys_dev, float* di
 
 extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
     HRS_REQUIRE(ctx && out, "hrs_score_stats: null argument");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
     HRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     int64_t h[8];
     HRS_CHECK_HIP(hipMemcpy(h, ctx->stats_dev, sizeof(h), hipMemcpyDeviceToHost));
@@ -407,6 +409,7 @@ extern "C" int hrs_score_stats(hrs_ctx* ctx, void* stream, int64_t out[3]) {
 
 extern "C" int hrs_scan_work(hrs_ctx* ctx, void* stream, double* main_pass_share) {
     HRS_REQUIRE(ctx && main_pass_share, "hrs_scan_work: null argument");
+    HRS_CHECK_HIP(hipSetDevice(ctx->device));
     HRS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     int64_t scored = 0;
     HRS_CHECK_HIP(hipMemcpy(&scored, ctx->stats_dev + 8, sizeof(scored), hipMemcpyDeviceToHost));
