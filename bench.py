@@ -498,8 +498,9 @@ def timed_run(engines, corpus, postings, group, queries, q_terms, q_offs, n_keep
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    # (the chip's clock settles over the first eight or so main passes of a run: 3.1 -> 2.75 ms in a kernel trace)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
