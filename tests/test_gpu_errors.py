@@ -80,3 +80,41 @@ def test_wrapper_raises_hrs_error(eng):
     d, r = eng.score_topk(corpus, q, 3)
     assert r.shape == (2, 3)
     corpus.close()
+
+
+def test_bad_arguments_of_the_rerank_entry_points(eng):
+    """The fusion / re-rank entry points (keyword classes, BM25 scores, fusion with given scores, the merge with 64-bit
+    payloads) reject sizes their kernels are not built for before anything is launched."""
+    L = N.lib()
+    f8 = C.c_double
+    keys = torch.zeros(4 * 300, dtype=torch.int64, device="cuda")
+    i32 = torch.zeros(4 * 300, dtype=torch.int32, device="cuda")
+    f32 = torch.zeros(4 * 300, dtype=torch.float32, device="cuda")
+    f64 = torch.zeros(4 * 300, dtype=torch.float64, device="cuda")
+    offs = torch.zeros(5, dtype=torch.int32, device="cuda")
+    # levels * k beyond one block of 256 candidates
+    assert L.hrs_classes_finish(eng._ctx, _p(keys), _p(offs), 4, 9, 30, f8(0.3), 5, _p(keys), _p(f32), _p(i32), _p(f64), None) == ERR_ARG
+    assert "levels * k" in N.last_error()
+    assert L.hrs_classes_finish(eng._ctx, None, _p(offs), 4, 2, 3, f8(0.3), 5, _p(keys), _p(f32), _p(i32), _p(f64), None) == ERR_ARG
+    assert L.hrs_classes_finish(eng._ctx, _p(keys), _p(offs), 4, 2, 3, f8(0.3), 0, _p(keys), _p(f32), _p(i32), _p(f64), None) == ERR_ARG
+    # fusion with given keyword scores: at most 256 candidates, at least one result
+    assert L.hrs_fuse_sort_scores(eng._ctx, _p(f32), _p(f64), 4, 257, f8(0.3), 5, _p(f64), _p(i32), None) == ERR_ARG
+    assert "c=257" in N.last_error()
+    assert L.hrs_fuse_sort_scores(eng._ctx, _p(f32), None, 4, 20, f8(0.3), 5, _p(f64), _p(i32), None) == ERR_ARG
+    # the merge with 64-bit payloads: payload and both outputs are required, G * k <= 2048
+    assert L.hrs_merge_topk_i64(eng._ctx, _p(keys), None, 2, 4, 10, _p(keys), _p(keys), None) == ERR_ARG
+    assert L.hrs_merge_topk_i64(eng._ctx, _p(keys), _p(keys), 300, 4, 10, _p(keys), _p(keys), None) == ERR_ARG
+    assert "G*k" in N.last_error()
+    # BM25: statistics that make no sense
+    terms = torch.zeros(8, dtype=torch.int32, device="cuda")
+    doc_offs = torch.arange(0, 9, 2, dtype=torch.int64, device="cuda")
+    post = eng.postings(doc_offs, terms)
+    rows = torch.zeros((4, 3), dtype=torch.int64, device="cuda")
+    bm = lambda avg, k1, b, idf=_p(f64): L.hrs_bm25_scores(eng._ctx, post._h, idf, 10, f8(avg), f8(k1), f8(b), _p(terms), _p(offs), _p(rows), 4, 3, _p(f64), None)
+    assert bm(0.0, 1.2, 0.75) == ERR_ARG and "avg_len" in N.last_error()
+    assert bm(2.0, -1.0, 0.75) == ERR_ARG
+    assert bm(2.0, 1.2, 1.5) == ERR_ARG
+    assert bm(2.0, 1.2, 0.75, idf=None) == ERR_ARG
+    assert bm(2.0, 1.2, 0.75) == 0  # and a good call still goes through
+    torch.cuda.synchronize()
+    post.close()
