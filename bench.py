@@ -201,7 +201,7 @@ def bench_scan(eng, corpus, queries, k=10):
     return out
 
 
-def bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep, k1=1.2, b=0.75):
+def bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep, k1=1.2, b=0.75, engines=None):
     """The headline's hybrid step with BM25 weights in the place of the keyword fraction (an extension: the reference
     scores the fraction of keywords present): top-2n by distance, BM25 of the candidates from their term lists (term
     frequency, list length, idf from the document frequencies of the inverted postings), fusion, first n.  Checked on
@@ -248,13 +248,32 @@ def bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep, k
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    out = {"queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
+           "config": f"sequential calls: top-{2 * n_keep} by distance over {n} x {corpus.dim}, BM25 (k1 {k1}, b {b}) of the candidates over their term lists, fusion -> top-{n_keep}",
+           "checked": "3 queries: BM25 weights and fused order equal Python-float arithmetic bit for bit"}
+    if engines is not None and len(engines) > 1:
+        # the same step through the two-stream pipeline of the headline (the scan of batch i + 1 beside the tail of batch i)
+        pipe = HybridPipeline(engines, corpus, postings, group=False)
+        step = lambda: pipe.submit(queries, q_terms, q_offs, n_keep, bm25=par)
+        for _ in range(4):
+            step()
+        pipe.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        last = pipe.drain()
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / reps
+        if not (torch.equal(last["perm"], run()["perm"])):
+            raise SystemExit("BM25 hybrid step: the pipelined batch differs from the single call")
+        out["pipelined_ms_per_batch"] = dtp * 1e3
+        out["pipelined_queries_per_s"] = B / dtp
     postings.close()
-    return {"queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B,
-            "config": f"sequential calls: top-{2 * n_keep} by distance over {n} x {corpus.dim}, BM25 (k1 {k1}, b {b}) of the candidates over their term lists, fusion -> top-{n_keep}",
-            "checked": "3 queries: BM25 weights and fused order equal Python-float arithmetic bit for bit"}
+    return out
 
 
-def bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep, B=64):
+def bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep, B=64, engines=None):
     """The full-corpus hybrid mode (an extension: the fused score over EVERY row, not over the 2n nearest) at the
     headline's size: match counts of all rows from inverted postings, the nearest n of every match-count class -- all
     classes of four queries in one fp64 pass over the fp32 corpus -- and the fusion.  Checked on the first query: the
@@ -286,7 +305,7 @@ def bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep, B=64
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     levels = int((qo[1:] - qo[:-1]).max().item()) + 1
-    bm25 = bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep)
+    bm25 = bench_bm25_step(eng, corpus, terms, inv, queries, q_terms, q_offs, n_keep, engines=engines)
     inv.close()
     passes = (B + 3) // 4
     return {"bm25_hybrid_step": bm25, "queries_per_s": B / dt, "ms_per_batch": dt * 1e3, "batch": B, "classes": levels, "corpus_passes": passes,
@@ -656,7 +675,7 @@ def main():
             extras["text_queries_end_to_end"] = bench_text_queries(eng, ShardedHybrid(eng, corpus, postings, group=False), n_keep)
             extras["embed"] = bench_embed(eng, cpu_chunks=0 if args.no_cpu_baseline else 2048)
             extras["exact_scan"] = bench_scan(eng, corpus, queries)
-            extras["full_corpus_hybrid"] = bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep)
+            extras["full_corpus_hybrid"] = bench_full_corpus(eng, corpus, terms, queries, q_terms, q_offs, n_keep, engines=engines)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(matrix, terms, queries, q_terms, q_offs, n_keep, n_total, args.cpu_sample_rows, args.cpu_sample_queries)
         else:
