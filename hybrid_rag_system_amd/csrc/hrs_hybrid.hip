@@ -88,13 +88,17 @@ __global__ __launch_bounds__(256) void k_bm25_scores(const int64_t* __restrict__
                     if (lane == j) tf += hits;
                 }
             }
-            for (int j = 0; j < nt; ++j) {  // in query order (wave-uniform values; lane 0's copy is the one kept)
-                const int qt = __builtin_amdgcn_readlane(my, j);
-                const int f = __builtin_amdgcn_readlane(tf, j);
-                if (qt < 0 || qt >= V) continue;
-                const double w = idf[qt];
-                best = __dadd_rn(best, __dmul_rn(w, k1p));
-                if (f > 0) score = __dadd_rn(score, __ddiv_rn(__dmul_rn(__dmul_rn(w, (double)f), k1p), __dadd_rn((double)f, norm)));
+            // lane j works out the contribution of term j (the division: once per wave, not once per term), then the
+            // contributions are added in query order; a term that is absent or outside the vocabulary adds an exact 0.0
+            double wk = 0.0, contrib = 0.0;
+            if (my >= 0 && my < V) {
+                const double w = idf[my];
+                wk = __dmul_rn(w, k1p);
+                if (tf > 0) contrib = __ddiv_rn(__dmul_rn(__dmul_rn(w, (double)tf), k1p), __dadd_rn((double)tf, norm));
+            }
+            for (int j = 0; j < nt; ++j) {  // (wave-uniform sums; lane 0's copy is the one kept)
+                best = __dadd_rn(best, __shfl(wk, j));
+                score = __dadd_rn(score, __shfl(contrib, j));
             }
         }
     }
